@@ -1,0 +1,138 @@
+/*
+ * igx.h - C ABI of libigx.so: fused per-step observation / reward / reset
+ * kernels for vectorised RL tasks on AMD MI355X (gfx950).
+ *
+ * Every entry point replaces a group of module-level @torch.jit.script
+ * functions plus the in-place bookkeeping of one task class of the reference
+ * (IsaacGymEnvs fork, paths relative to IsaacGymEnvs/isaacgymenvs/).  The
+ * reference has no FFI for this path (it is Python calling ATen); the
+ * signatures below are what a ctypes binding on the reference side binds.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers on the current HIP device unless a field
+ *    says "host".  The library borrows them for the duration of the (async)
+ *    launch and never allocates or frees caller memory.
+ *  - Work is enqueued on the caller's stream (hipStream_t passed as void*,
+ *    NULL = the default stream).  No entry point synchronises the device.
+ *  - Layouts are the reference's: root / rigid-body state rows are 13 floats
+ *    (pos 3, quat xyzw 4, lin vel 3, ang vel 3); dof_state is [N, D, 2]
+ *    interleaved (pos, vel); flag buffers are int64.
+ *  - Return value: 0 = ok, negative = IGX_E_* argument error (nothing was
+ *    launched), positive = hipError_t of the failed launch.
+ *    igx_last_error_string() describes the last error of the calling thread.
+ */
+#ifndef IGX_H
+#define IGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGX_OK 0
+#define IGX_E_NULL (-1)    /* a required pointer is NULL */
+#define IGX_E_SIZE (-2)    /* a count is negative or too large */
+#define IGX_E_PARAM (-3)   /* a parameter is outside what the kernels support */
+#define IGX_E_ALIGN (-4)   /* a pointer is not aligned as documented */
+#define IGX_E_NODEVICE (-5) /* no usable HIP device */
+
+#define IGX_MAX_DOF 32
+
+typedef void *igx_stream_t; /* hipStream_t */
+
+/* Library identification and error text (no reference counterpart). */
+int igx_version(void);
+const char *igx_last_error_string(void);
+
+/* ------------------------------------------------------------------------
+ * Cartpole: one fused post_physics_step.
+ * Replaces tasks/cartpole.py:170-178 (post_physics_step), :148-162
+ * (reset_idx), :135-146 (compute_observations) and :185-201
+ * (compute_cartpole_reward).
+ * Order per env: progress += 1; if reset != 0 { dof_pos = 0.9*(u-0.5),
+ * dof_vel = 0.5*(u-0.5), reset = progress = 0 }; obs = dof_state row;
+ * reward / reset decision.
+ * ---------------------------------------------------------------------- */
+typedef struct igx_cartpole_params {
+    float reset_dist;             /* env.resetDist, 3.0 */
+    float max_episode_length_m1;  /* max_episode_length - 1 = 499 */
+    uint64_t seed;                /* in-kernel Philox key when rand == NULL */
+    uint64_t rng_offset;          /* step counter mixed into the Philox counter */
+} igx_cartpole_params;
+
+typedef struct igx_cartpole_buffers {
+    float *dof_state;    /* [N,2,2] in/out (rewritten only for reset envs) */
+    const float *rand;   /* [N,4] uniforms in [0,1): pos0,pos1,vel0,vel1; NULL = Philox */
+    float *obs;          /* [N,4] out */
+    float *rew;          /* [N] out */
+    int64_t *reset;      /* [N] in/out */
+    int64_t *progress;   /* [N] in/out */
+} igx_cartpole_buffers;
+
+int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *b,
+                      int64_t n_envs, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Ant / Humanoid locomotion: one fused post_physics_step.
+ * Ant:      tasks/ant.py:376-386 (post_physics_step), :339-366 (reset_idx),
+ *           :463-497 (compute_ant_observations), :414-460 (compute_ant_reward),
+ *           :332-337 (compute_true_objective).
+ * Humanoid: tasks/humanoid.py:398-407, :360-390, :489-524, :434-486.
+ * Shared helpers: utils/torch_jit_utils.py:41-62 quat_mul, :65-67 normalize,
+ * :80-103 quat_rotate(_inverse), :175-195 get_euler_xyz, :239-241 unscale,
+ * :248-277 compute_heading_and_up / compute_rot, :126-128 normalize_angle.
+ * ---------------------------------------------------------------------- */
+typedef struct igx_loco_params {
+    int32_t num_dof;            /* 8 (Ant) or 21 (Humanoid) */
+    int32_t num_sensor_floats;  /* 24 (Ant: 4 sensors x 6) or 12 (Humanoid) */
+    float dt;                   /* sim.dt 0.0166 */
+    float dof_vel_scale;        /* 0.2 Ant, 0.1 Humanoid */
+    float contact_force_scale;  /* 0.1 Ant, 0.01 Humanoid */
+    float angular_velocity_scale; /* Humanoid 0.25 (Ant: unused) */
+    float up_weight, heading_weight;
+    float actions_cost_scale, energy_cost_scale, joints_at_limit_cost_scale;
+    float termination_height, death_cost;
+    float max_episode_length_m1; /* episodeLength - 1 */
+    float targets[3];            /* [1000,0,0] */
+    float inv_start_rot[4];      /* conj(start_rotation), xyzw */
+    float basis_vec0[3];         /* heading basis [1,0,0] */
+    float basis_vec1[3];         /* up basis [0,0,1] */
+    float dof_limits_lower[IGX_MAX_DOF];
+    float dof_limits_upper[IGX_MAX_DOF];
+    float motor_efforts[IGX_MAX_DOF]; /* Humanoid only */
+    float max_motor_effort;           /* Humanoid only */
+    uint64_t seed;
+    uint64_t rng_offset;
+} igx_loco_params;
+
+typedef struct igx_loco_buffers {
+    const float *root_states;         /* [N,13] */
+    float *dof_state;                 /* [N,D,2] in/out (rewritten only for reset envs) */
+    const float *dof_force;           /* [N,D] Humanoid; NULL for Ant */
+    const float *sensors;             /* [N,num_sensor_floats] */
+    const float *actions;             /* [N,D] */
+    const float *initial_root_states; /* [N,13] read for reset envs only */
+    const float *initial_dof_pos;     /* [N,D]  read for reset envs only */
+    const float *rand;                /* [N,2D] uniforms in [0,1): D position draws then D velocity draws; NULL = Philox */
+    float *obs;                       /* [N,60] Ant / [N,108] Humanoid, out */
+    float *potentials;                /* [N] in/out */
+    float *prev_potentials;           /* [N] out */
+    float *up_vec;                    /* [N,3] out */
+    float *heading_vec;               /* [N,3] out */
+    float *rew;                       /* [N] out */
+    int64_t *reset;                   /* [N] in/out */
+    int64_t *progress;                /* [N] in/out */
+    int64_t *randomize;               /* [N] in/out, += 1; may be NULL */
+    float *true_objective;            /* [N] out (Ant extras['true_objective']); may be NULL */
+} igx_loco_buffers;
+
+int igx_ant_step(const igx_loco_params *p, const igx_loco_buffers *b,
+                 int64_t n_envs, igx_stream_t stream);
+int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b,
+                      int64_t n_envs, igx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGX_H */

@@ -1,0 +1,94 @@
+"""ctypes mirror of include/igx.h (struct layouts and constants only).
+
+No library is loaded here; isaacgym_amd._lib loads libigx.so.  Field order and
+types must match the header exactly.
+"""
+import ctypes as C
+
+IGX_MAX_DOF = 32
+
+IGX_OK = 0
+IGX_E_NULL = -1
+IGX_E_SIZE = -2
+IGX_E_PARAM = -3
+IGX_E_ALIGN = -4
+IGX_E_NODEVICE = -5
+
+f32 = C.c_float
+i32 = C.c_int32
+i64 = C.c_int64
+u64 = C.c_uint64
+ptr = C.c_void_p
+
+
+class _Struct(C.Structure):
+    def __init__(self, **kw):
+        super().__init__()
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, k, v):
+        cur = getattr(self, k)
+        if isinstance(cur, C.Array):
+            v = list(v)
+            if len(v) > len(cur):
+                raise ValueError("%s: %d values for %d slots" % (k, len(v), len(cur)))
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(self, k, v)
+
+
+class CartpoleParams(_Struct):
+    _fields_ = [("reset_dist", f32), ("max_episode_length_m1", f32),
+                ("seed", u64), ("rng_offset", u64)]
+
+
+class CartpoleBuffers(_Struct):
+    _fields_ = [("dof_state", ptr), ("rand", ptr), ("obs", ptr), ("rew", ptr),
+                ("reset", ptr), ("progress", ptr)]
+
+
+class LocoParams(_Struct):
+    _fields_ = [("num_dof", i32), ("num_sensor_floats", i32),
+                ("dt", f32), ("dof_vel_scale", f32), ("contact_force_scale", f32),
+                ("angular_velocity_scale", f32),
+                ("up_weight", f32), ("heading_weight", f32),
+                ("actions_cost_scale", f32), ("energy_cost_scale", f32),
+                ("joints_at_limit_cost_scale", f32),
+                ("termination_height", f32), ("death_cost", f32),
+                ("max_episode_length_m1", f32),
+                ("targets", f32 * 3), ("inv_start_rot", f32 * 4),
+                ("basis_vec0", f32 * 3), ("basis_vec1", f32 * 3),
+                ("dof_limits_lower", f32 * IGX_MAX_DOF),
+                ("dof_limits_upper", f32 * IGX_MAX_DOF),
+                ("motor_efforts", f32 * IGX_MAX_DOF),
+                ("max_motor_effort", f32),
+                ("seed", u64), ("rng_offset", u64)]
+
+
+class LocoBuffers(_Struct):
+    _fields_ = [("root_states", ptr), ("dof_state", ptr), ("dof_force", ptr),
+                ("sensors", ptr), ("actions", ptr),
+                ("initial_root_states", ptr), ("initial_dof_pos", ptr), ("rand", ptr),
+                ("obs", ptr), ("potentials", ptr), ("prev_potentials", ptr),
+                ("up_vec", ptr), ("heading_vec", ptr), ("rew", ptr),
+                ("reset", ptr), ("progress", ptr), ("randomize", ptr),
+                ("true_objective", ptr)]
+
+
+def make_buffers(cls, arrays, ptr_of):
+    """Build a *Buffers struct from a name->array mapping.
+
+    ptr_of(array) returns the raw address; missing / None entries become NULL.
+    Unknown names raise so that a typo cannot silently drop a buffer.
+    """
+    names = {n for n, _ in cls._fields_}
+    for k in arrays:
+        if k not in names:
+            raise KeyError("%s has no buffer named %r" % (cls.__name__, k))
+    b = cls()
+    for n in names:
+        a = arrays.get(n)
+        setattr(b, n, None if a is None else ptr_of(a))
+    return b

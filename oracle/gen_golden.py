@@ -1,0 +1,321 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/gen_golden.py [task ...]
+
+For every task the reference's task class is instantiated without its
+constructor (PhysX is absent), given synthetic state tensors, and its own
+post_physics_step / pre_physics_step / reset_idx methods are executed on CPU.
+Inputs, the uniforms torch drew inside reset_idx, and all resulting buffers
+are stored as small .npz files.  The fixtures hold data only - no reference
+source text.  torch version and parameters are recorded in each file.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+CFG = os.path.join(ref_shim.IGE, "cfg", "task")
+
+
+class _Any:
+    def __getattr__(self, k):
+        return _Any()
+
+    def __call__(self, *a, **k):
+        return _Any()
+
+
+def _cfg(name):
+    with open(os.path.join(CFG, name + ".yaml")) as f:
+        return yaml.safe_load(f)
+
+
+def _meta(**kw):
+    kw["torch"] = torch.__version__
+    kw["cpu_capability"] = torch.backends.cpu.get_cpu_capability()
+    return json.dumps(kw)
+
+
+def _rand_quat(g, n):
+    """half random unit quaternions, half small perturbations of identity
+    (roll / yaw near 0 exercise the remainder wrap)."""
+    q = torch.randn(n, 4, generator=g)
+    small = torch.randn(n, 4, generator=g) * 1e-3
+    small[:, 3] = 1.0
+    pick = torch.rand(n, generator=g) < 0.5
+    q = torch.where(pick.unsqueeze(-1), q, small)
+    # a few exact identities and exact axis flips
+    q[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    q[1] = torch.tensor([0.0, 0.0, 1.0, 0.0])
+    q[2] = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def _install_gym_stubs():
+    ref_shim.install()
+    gt = sys.modules["isaacgym.gymtorch"]
+    gt.unwrap_tensor = lambda t: t
+    gt.wrap_tensor = lambda t: t
+
+
+def _replay_uniforms(state, shapes):
+    """Re-draw what torch.rand produced after RNG state `state`."""
+    keep = torch.get_rng_state()
+    torch.set_rng_state(state)
+    out = [torch.rand(*s) for s in shapes]
+    torch.set_rng_state(keep)
+    return out
+
+
+# --------------------------------------------------------------------------
+def gen_cartpole(seed=0, N=4096, T=4):
+    _install_gym_stubs()
+    mod = ref_shim.load("isaacgymenvs.tasks.cartpole")
+    cfg = _cfg("Cartpole")
+
+    class Fake(mod.Cartpole):
+        def __init__(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    t = Fake()
+    t.cfg = cfg
+    t.reset_dist = cfg["env"]["resetDist"]
+    t.max_episode_length = 500
+    t.num_envs, t.num_dof, t.device = N, 2, "cpu"
+    t.gym, t.sim = _Any(), None
+    t.dof_state = torch.zeros(N * 2, 2)
+    t.dof_pos = t.dof_state.view(N, 2, 2)[..., 0]
+    t.dof_vel = t.dof_state.view(N, 2, 2)[..., 1]
+    t.obs_buf = torch.zeros(N, 4)
+    t.rew_buf = torch.zeros(N)
+    t.reset_buf = torch.ones(N, dtype=torch.long)
+    t.progress_buf = torch.randint(0, 500, (N,), generator=g)
+    t.progress_buf[:8] = torch.tensor([496, 497, 498, 499, 500, 0, 1, 2])
+
+    rec = {k: [] for k in ("in_dof_state", "rand", "out_dof_state", "obs", "rew", "reset", "progress")}
+    init = {"reset0": t.reset_buf.numpy().copy(), "progress0": t.progress_buf.numpy().copy()}
+    torch.manual_seed(seed + 100)
+    for step in range(T):
+        ds = torch.empty(N, 2, 2)
+        ds[:, 0, 0] = (torch.rand(N, generator=g) * 2 - 1) * 3.5
+        ds[:, 1, 0] = (torch.rand(N, generator=g) * 2 - 1) * 2.0
+        ds[:, :, 1] = torch.randn(N, 2, generator=g)
+        ds[0, 0, 0] = 3.0       # exactly resetDist: not > 3.0
+        ds[1, 1, 0] = math.pi / 2  # float32(pi/2): not > float32(pi/2)
+        t.dof_state.copy_(ds.view(N * 2, 2))
+        rec["in_dof_state"].append(t.dof_state.numpy().copy())
+        ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        st = torch.get_rng_state()
+        t.post_physics_step()
+        dense = np.zeros((N, 4), np.float32)
+        if len(ids) > 0:
+            up, uv = _replay_uniforms(st, [(len(ids), 2), (len(ids), 2)])
+            dense[ids.numpy(), 0:2] = up.numpy()
+            dense[ids.numpy(), 2:4] = uv.numpy()
+        rec["rand"].append(dense)
+        rec["out_dof_state"].append(t.dof_state.numpy().copy())
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(init)
+    out["meta"] = _meta(task="Cartpole", N=N, T=T, seed=seed, reset_dist=t.reset_dist,
+                        max_episode_length=t.max_episode_length)
+    np.savez_compressed(os.path.join(OUT, "cartpole.npz"), **out)
+    print("cartpole.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+# --------------------------------------------------------------------------
+def _loco_common(t, cfg, N, D, g, z_mean):
+    e = cfg["env"]
+    t.cfg = cfg
+    t.max_episode_length = e["episodeLength"]
+    t.randomize = False
+    t.dof_vel_scale = e["dofVelocityScale"]
+    t.contact_force_scale = e["contactForceScale"]
+    t.power_scale = e["powerScale"]
+    t.heading_weight = e["headingWeight"]
+    t.up_weight = e["upWeight"]
+    t.actions_cost_scale = e["actionsCost"]
+    t.energy_cost_scale = e["energyCost"]
+    t.joints_at_limit_cost_scale = e["jointsAtLimitCost"]
+    t.death_cost = e["deathCost"]
+    t.termination_height = e["terminationHeight"]
+    t.debug_viz = False
+    t.viewer = None
+    t.num_envs, t.num_dof, t.device = N, D, "cpu"
+    t.gym, t.sim = _Any(), None
+    t.up_axis_idx = 2
+    t.extras = {}
+    # synthetic joint limits (the asset files are not in the reference tree);
+    # one joint with lower > 0 and one with upper < 0 exercise initial_dof_pos
+    lo = torch.tensor([-0.5 - 0.05 * j for j in range(D)])
+    hi = torch.tensor([0.6 + 0.03 * j for j in range(D)])
+    lo[1], hi[1] = 0.1, 0.9
+    lo[2], hi[2] = -0.9, -0.1
+    t.dof_limits_lower, t.dof_limits_upper = lo, hi
+    t.root_states = torch.zeros(N, 13)
+    t.initial_root_states = torch.zeros(N, 13)
+    t.initial_root_states[:, 0:2] = torch.randn(N, 2, generator=g) * 0.05
+    t.initial_root_states[:, 2] = z_mean
+    t.initial_root_states[:, 6] = 1.0
+    t.dof_state = torch.zeros(N * D, 2)
+    t.dof_pos = t.dof_state.view(N, D, 2)[..., 0]
+    t.dof_vel = t.dof_state.view(N, D, 2)[..., 1]
+    # ant.py:114-117 / humanoid.py:114-117
+    zero = torch.tensor([0.0])
+    t.initial_dof_pos = torch.zeros(N, D)
+    t.initial_dof_pos = torch.where(lo > zero, lo, torch.where(hi < zero, hi, t.initial_dof_pos))
+    t.start_rotation = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    t.up_vec = torch.tensor([0.0, 0.0, 1.0]).repeat(N, 1)
+    t.heading_vec = torch.tensor([1.0, 0.0, 0.0]).repeat(N, 1)
+    t.inv_start_rot = tj.quat_conjugate(t.start_rotation).repeat(N, 1)
+    t.basis_vec0 = t.heading_vec.clone()
+    t.basis_vec1 = t.up_vec.clone()
+    t.targets = torch.tensor([1000.0, 0.0, 0.0]).repeat(N, 1)
+    t.dt = cfg["sim"]["dt"]
+    t.potentials = torch.tensor([-1000.0 / t.dt]).repeat(N)
+    t.prev_potentials = t.potentials.clone()
+    t.rew_buf = torch.zeros(N)
+    t.reset_buf = torch.ones(N, dtype=torch.long)
+    t.progress_buf = torch.randint(0, 1000, (N,), generator=g)
+    t.progress_buf[:6] = torch.tensor([996, 997, 998, 999, 1000, 0])
+    t.randomize_buf = torch.zeros(N, dtype=torch.long)
+
+
+def _loco_inputs(t, N, D, S, g, z_mean, z_std, with_force):
+    root = torch.empty(N, 13)
+    root[:, 0:3] = torch.randn(N, 3, generator=g) * 0.1
+    root[:, 2] = z_mean + torch.randn(N, generator=g) * z_std
+    root[:, 3:7] = _rand_quat(g, N)
+    root[:, 7:13] = torch.randn(N, 6, generator=g)
+    root[3, 2] = t.termination_height  # float32(h) < h(double->f32) is False
+    root[4, 0] = 1000.0                # to_target == 0 -> normalize clamps at 1e-9
+    root[4, 1] = 0.0
+    t.root_states.copy_(root)
+    lo, hi = t.dof_limits_lower, t.dof_limits_upper
+    u = torch.rand(N, D, generator=g) * 1.06 - 0.03  # a few % beyond the limits
+    pos = lo + (hi - lo) * u
+    vel = torch.randn(N, D, generator=g)
+    t.dof_state.view(N, D, 2)[..., 0] = pos
+    t.dof_state.view(N, D, 2)[..., 1] = vel
+    t.vec_sensor_tensor = torch.randn(N, S, generator=g) * 10
+    t.actions = torch.rand(N, D, generator=g) * 2 - 1
+    if with_force:
+        t.dof_force_tensor = torch.randn(N, D, generator=g) * 30
+
+
+def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T):
+    _install_gym_stubs()
+    mod = ref_shim.load(modname)
+    cfg = _cfg(cfgname)
+    Base = getattr(mod, clsname)
+
+    class Fake(Base):
+        def __init__(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    t = Fake()
+    z_mean, z_std = (1.34, 0.3) if humanoid else (0.55, 0.1)
+    _loco_common(t, cfg, N, D, g, z_mean)
+    nobs = 108 if humanoid else 60
+    t.obs_buf = torch.zeros(N, nobs)
+    if humanoid:
+        t.angular_velocity_scale = cfg["env"].get("angularVelocityScale", 0.1)
+        efforts = (torch.rand(D, generator=g) * 180 + 20).tolist()
+        t.max_motor_effort = max(efforts)
+        t.motor_efforts = torch.tensor(efforts)
+
+    keys = ["in_root", "in_dof_state", "in_sensors", "in_actions", "rand", "out_dof_state", "obs",
+            "potentials", "prev_potentials", "up_vec", "heading_vec", "rew", "reset", "progress",
+            "randomize"]
+    if humanoid:
+        keys.append("in_dof_force")
+    else:
+        keys.append("true_objective")
+    rec = {k: [] for k in keys}
+    init = {"reset0": t.reset_buf.numpy().copy(), "progress0": t.progress_buf.numpy().copy(),
+            "potentials0": t.potentials.numpy().copy(),
+            "initial_root_states": t.initial_root_states.numpy().copy(),
+            "initial_dof_pos": t.initial_dof_pos.numpy().copy(),
+            "dof_limits_lower": t.dof_limits_lower.numpy().copy(),
+            "dof_limits_upper": t.dof_limits_upper.numpy().copy()}
+    if humanoid:
+        init["motor_efforts"] = t.motor_efforts.numpy().copy()
+    torch.manual_seed(seed + 100)
+    for step in range(T):
+        _loco_inputs(t, N, D, S, g, z_mean, z_std, humanoid)
+        rec["in_root"].append(t.root_states.numpy().copy())
+        rec["in_dof_state"].append(t.dof_state.numpy().copy())
+        rec["in_sensors"].append(t.vec_sensor_tensor.numpy().copy())
+        rec["in_actions"].append(t.actions.numpy().copy())
+        if humanoid:
+            rec["in_dof_force"].append(t.dof_force_tensor.numpy().copy())
+        ids = t.reset_buf.nonzero(as_tuple=False).flatten()
+        st = torch.get_rng_state()
+        t.post_physics_step()
+        dense = np.zeros((N, 2 * D), np.float32)
+        if len(ids) > 0:
+            up, uv = _replay_uniforms(st, [(len(ids), D), (len(ids), D)])
+            dense[ids.numpy(), :D] = up.numpy()
+            dense[ids.numpy(), D:] = uv.numpy()
+        rec["rand"].append(dense)
+        rec["out_dof_state"].append(t.dof_state.numpy().copy())
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["potentials"].append(t.potentials.numpy().copy())
+        rec["prev_potentials"].append(t.prev_potentials.numpy().copy())
+        rec["up_vec"].append(t.up_vec.numpy().copy())
+        rec["heading_vec"].append(t.heading_vec.numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+        rec["randomize"].append(t.randomize_buf.numpy().copy())
+        if not humanoid:
+            rec["true_objective"].append(t.extras["true_objective"].numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(init)
+    e = cfg["env"]
+    meta = dict(task=cfgname, N=N, T=T, seed=seed, num_dof=D, num_sensor_floats=S, dt=cfg["sim"]["dt"],
+                dof_vel_scale=e["dofVelocityScale"], contact_force_scale=e["contactForceScale"],
+                angular_velocity_scale=e.get("angularVelocityScale", 0.1),
+                up_weight=e["upWeight"], heading_weight=e["headingWeight"],
+                actions_cost_scale=e["actionsCost"], energy_cost_scale=e["energyCost"],
+                joints_at_limit_cost_scale=e["jointsAtLimitCost"],
+                termination_height=e["terminationHeight"], death_cost=e["deathCost"],
+                max_episode_length=e["episodeLength"])
+    if humanoid:
+        meta["max_motor_effort"] = t.max_motor_effort
+    out["meta"] = _meta(**meta)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+def gen_ant(seed=1, N=449, T=4):
+    _gen_loco("ant", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, seed, N, T)
+
+
+def gen_humanoid(seed=2, N=211, T=4):
+    _gen_loco("humanoid", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, seed, N, T)
+
+
+GENERATORS = {"cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid}
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    names = sys.argv[1:] or list(GENERATORS)
+    for n in names:
+        GENERATORS[n]()

@@ -1,0 +1,397 @@
+/*
+ * igx_oracle.c - CPU restatement of the reference's per-step tensor path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker the GPU kernels are
+ * compared against; it is never linked into, imported by or called from the
+ * product library (libigx.so) or the isaacgym_amd package.  Only tests/,
+ * __graft_entry__.smoke() and the cpu_baseline leg of bench.py load it.
+ *
+ * It restates, one environment at a time in scalar fp32, what the reference's
+ * torch.jit functions compute on CPU.  Every ATen op rounds its result to
+ * fp32, so each C expression below is one rounding per operation (compile with
+ * -ffp-contract=off); fmaf() appears exactly where the ATen CPU kernel fuses
+ * (cross product, vector norm).  Parity pin: tests/golden/*.npz, produced by
+ * oracle/gen_golden.py from the reference's own functions
+ * (torch 2.10.0 CPU) - see tests/test_oracle_golden.py.
+ *
+ * Paths cited are relative to IsaacGymEnvs/isaacgymenvs/ in the reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#include "../include/igx.h"
+
+#define TWO_PI_F 6.2831855f /* float32(2*np.pi) */
+
+/* ---------------------------------------------------------------- RNG --- */
+/* Philox4x32-10 (Salmon et al. 2011), the counter-based generator the
+ * library uses when no pre-drawn uniforms are supplied.  Not part of the
+ * reference (which draws torch.rand of a data-dependent shape); restated here
+ * so the in-kernel draw can be checked bit for bit. */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+/* j-th uniform in [0,1) of environment `env` at step `offset`. */
+float orc_philox_uniform(uint64_t seed, uint64_t offset, int64_t env, int j)
+{
+    uint32_t c[4];
+    c[0] = (uint32_t)(uint64_t)env;
+    c[1] = (uint32_t)((uint64_t)env >> 32);
+    c[2] = (uint32_t)offset;
+    c[3] = (((uint32_t)(offset >> 32) & 0xFFFFFFu) << 8) | (uint32_t)(j >> 2);
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (float)(c[j & 3] >> 8) * (1.0f / 16777216.0f);
+}
+
+static float draw(const float *rand, int64_t e, int per_env, int j, uint64_t seed, uint64_t off)
+{
+    return rand ? rand[e * per_env + j] : orc_philox_uniform(seed, off, e, j);
+}
+
+/* ------------------------------------------------------ math helpers --- */
+/* utils/torch_jit_utils.py:41-62 quat_mul (8-multiply form), xyzw order */
+static void quat_mul(const float a[4], const float b[4], float o[4])
+{
+    float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
+    float x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+    float ww = (z1 + x1) * (x2 + y2);
+    float yy = (w1 - y1) * (w2 + z2);
+    float zz = (w1 + y1) * (w2 - z2);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+    float w = qq - ww + (z1 - y1) * (y2 - z2);
+    float x = qq - xx + (x1 + w1) * (x2 + w2);
+    float y = qq - yy + (w1 - x1) * (y2 + z2);
+    float z = qq - zz + (z1 + y1) * (w2 - x2);
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+
+/* utils/torch_jit_utils.py:106-110 */
+static void quat_conjugate(const float a[4], float o[4])
+{
+    o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3];
+}
+
+/* torch.cross(a,b,dim=-1) on CPU: each component is one fused multiply-add */
+static void cross3(const float a[3], const float b[3], float o[3])
+{
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+
+/* torch.bmm([N,1,3],[N,3,1]) on CPU: plain left-to-right dot, no fusion,
+ * accumulated onto +0 (so an all-negative-zero product sum comes out +0) */
+static float dot3(const float a[3], const float b[3])
+{
+    return ((0.0f + a[0] * b[0]) + a[1] * b[1]) + a[2] * b[2];
+}
+
+/* torch.norm(x, p=2, dim=-1) of a 3-vector on CPU */
+static float norm3(const float v[3])
+{
+    float acc = v[0] * v[0];
+    acc = fmaf(v[1], v[1], acc);
+    acc = fmaf(v[2], v[2], acc);
+    return sqrtf(acc);
+}
+
+/* norm of a 4-vector (quat_unit inside quat_from_angle_axis); the ATen
+ * vectorised path is not a simple chain, so this feeds tolerance-class
+ * outputs only */
+static float norm4(const float v[4])
+{
+    float acc = v[0] * v[0];
+    acc = fmaf(v[1], v[1], acc);
+    acc = fmaf(v[2], v[2], acc);
+    acc = fmaf(v[3], v[3], acc);
+    return sqrtf(acc);
+}
+
+/* utils/torch_jit_utils.py:65-67 normalize: x / clamp(norm, min=1e-9) */
+static void normalize3(const float v[3], float o[3])
+{
+    float n = norm3(v);
+    if (n < 1e-9f) n = 1e-9f;
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+
+/* utils/torch_jit_utils.py:80-90 quat_rotate (sign=+1), :93-103
+ * quat_rotate_inverse (sign=-1), :411-421 my_quat_rotate (sign=+1) */
+static void quat_rotate_s(const float q[4], const float v[3], float o[3], int inverse)
+{
+    float qw = q[3];
+    float s = 2.0f * (qw * qw) - 1.0f;
+    float cr[3];
+    cross3(q, v, cr);
+    float d = dot3(q, v);
+    for (int i = 0; i < 3; ++i) {
+        float a = v[i] * s;
+        float b = cr[i] * qw * 2.0f;
+        float c = q[i] * d * 2.0f;
+        o[i] = inverse ? (a - b + c) : (a + b + c);
+    }
+}
+
+/* torch.remainder(x, float32(2*pi)) */
+static float remainder_2pi(float x)
+{
+    float m = fmodf(x, TWO_PI_F);
+    if (m != 0.0f && m < 0.0f) m += TWO_PI_F;
+    return m;
+}
+
+/* utils/torch_jit_utils.py:126-128 */
+static float normalize_angle(float x)
+{
+    return atan2f(sinf(x), cosf(x));
+}
+
+/* utils/torch_jit_utils.py:175-195 get_euler_xyz; only roll and yaw are
+ * consumed by the tasks on this path (pitch is computed and dropped) */
+static void euler_roll_yaw(const float q[4], float *roll, float *yaw)
+{
+    float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    float sinr_cosp = 2.0f * (qw * qx + qy * qz);
+    float cosr_cosp = qw * qw - qx * qx - qy * qy + qz * qz;
+    float siny_cosp = 2.0f * (qw * qz + qx * qy);
+    float cosy_cosp = qw * qw + qx * qx - qy * qy - qz * qz;
+    *roll = remainder_2pi(atan2f(sinr_cosp, cosr_cosp));
+    *yaw = remainder_2pi(atan2f(siny_cosp, cosy_cosp));
+}
+
+/* utils/torch_jit_utils.py:239-241 unscale */
+static float unscale1(float x, float lo, float hi)
+{
+    return (2.0f * x - hi - lo) / (hi - lo);
+}
+
+/* torch.sum(x, dim=-1) over a contiguous row of D floats on CPU: 8 vector
+ * lanes accumulate the full blocks of 8, the tail is summed first, then the
+ * lanes are added left to right. */
+static float row_sum(const float *x, int D)
+{
+    int nb = D / 8;
+    float lane[8];
+    if (nb == 0) {
+        float r = x[0];
+        for (int i = 1; i < D; ++i) r += x[i];
+        return r;
+    }
+    for (int l = 0; l < 8; ++l) {
+        float a = x[l];
+        for (int b = 1; b < nb; ++b) a += x[8 * b + l];
+        lane[l] = a;
+    }
+    int t = 8 * nb;
+    float r;
+    if (t < D) {
+        r = x[t];
+        for (int i = t + 1; i < D; ++i) r += x[i];
+        r += lane[0];
+    } else {
+        r = lane[0];
+    }
+    for (int l = 1; l < 8; ++l) r += lane[l];
+    return r;
+}
+
+/* ---------------------------------------------------------- Cartpole --- */
+/* tasks/cartpole.py:170-178, :148-162, :135-146, :185-201 */
+int orc_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *b, int64_t n)
+{
+    const float half_pi = 1.57079637f; /* float32(np.pi / 2) */
+    for (int64_t e = 0; e < n; ++e) {
+        float *ds = b->dof_state + e * 4;
+        int64_t prog = b->progress[e] + 1;
+        int64_t rst = b->reset[e];
+        if (rst != 0) {
+            float u0 = draw(b->rand, e, 4, 0, p->seed, p->rng_offset);
+            float u1 = draw(b->rand, e, 4, 1, p->seed, p->rng_offset);
+            float u2 = draw(b->rand, e, 4, 2, p->seed, p->rng_offset);
+            float u3 = draw(b->rand, e, 4, 3, p->seed, p->rng_offset);
+            ds[0] = 0.9f * (u0 - 0.5f);
+            ds[2] = 0.9f * (u1 - 0.5f);
+            ds[1] = 0.5f * (u2 - 0.5f);
+            ds[3] = 0.5f * (u3 - 0.5f);
+            rst = 0;
+            prog = 0;
+        }
+        float cart_pos = ds[0], cart_vel = ds[1], pole_angle = ds[2], pole_vel = ds[3];
+        float *o = b->obs + e * 4;
+        o[0] = cart_pos; o[1] = cart_vel; o[2] = pole_angle; o[3] = pole_vel;
+        float reward = 1.0f - pole_angle * pole_angle - 0.01f * fabsf(cart_vel) - 0.005f * fabsf(pole_vel);
+        if (fabsf(cart_pos) > p->reset_dist) reward = -2.0f;
+        if (fabsf(pole_angle) > half_pi) reward = -2.0f;
+        if (fabsf(cart_pos) > p->reset_dist) rst = 1;
+        if (fabsf(pole_angle) > half_pi) rst = 1;
+        if ((float)prog >= p->max_episode_length_m1) rst = 1;
+        b->rew[e] = reward;
+        b->reset[e] = rst;
+        b->progress[e] = prog;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------- Ant and Humanoid --- */
+/* tasks/ant.py:376-386, :339-366, :463-497, :414-460, :332-337 and
+ * tasks/humanoid.py:398-407, :360-390, :489-524, :434-486.
+ * humanoid != 0 selects the Humanoid observation layout and reward. */
+static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int humanoid)
+{
+    const int D = p->num_dof;
+    const int S = p->num_sensor_floats;
+    const int NOBS = humanoid ? 12 + 3 * D + S + D : 12 + 2 * D + S + D;
+    float ratio[IGX_MAX_DOF];
+    for (int j = 0; j < D; ++j) ratio[j] = humanoid ? p->motor_efforts[j] / p->max_motor_effort : 0.0f;
+
+    for (int64_t e = 0; e < n; ++e) {
+        const float *root = b->root_states + e * 13;
+        float *ds = b->dof_state + e * D * 2;
+        const float *act = b->actions + e * D;
+        float *obs = b->obs + e * NOBS;
+
+        int64_t prog = b->progress[e] + 1;
+        int64_t rst = b->reset[e];
+        float pot = b->potentials[e];
+        if (b->randomize) b->randomize[e] += 1;
+
+        if (rst != 0) { /* reset_idx */
+            for (int j = 0; j < D; ++j) {
+                float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset);
+                float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset);
+                /* torch_rand_float: (upper - lower) * rand + lower */
+                float pos = 0.4f * up + (-0.2f);
+                float vel = 0.2f * uv + (-0.1f);
+                float t = b->initial_dof_pos[e * D + j] + pos;
+                /* tensor_clamp: max(min(t, hi), lo) */
+                t = fminf(t, p->dof_limits_upper[j]);
+                t = fmaxf(t, p->dof_limits_lower[j]);
+                ds[2 * j] = t;
+                ds[2 * j + 1] = vel;
+            }
+            const float *ir = b->initial_root_states + e * 13;
+            float tt[3] = { p->targets[0] - ir[0], p->targets[1] - ir[1], 0.0f };
+            pot = -norm3(tt) / p->dt;
+            prog = 0;
+            rst = 0;
+        }
+
+        /* compute_*_observations */
+        float to_target[3] = { p->targets[0] - root[0], p->targets[1] - root[1], 0.0f };
+        float prev_pot = pot;
+        pot = -norm3(to_target) / p->dt;
+
+        float target_dirs[3];
+        normalize3(to_target, target_dirs);
+        float tq[4];
+        quat_mul(root + 3, p->inv_start_rot, tq);
+        float up_vec[3], heading_vec[3];
+        quat_rotate_s(tq, p->basis_vec1, up_vec, 0);
+        quat_rotate_s(tq, p->basis_vec0, heading_vec, 0);
+        float up_proj = up_vec[2];
+        float heading_proj = dot3(heading_vec, target_dirs);
+
+        float vel_loc[3], angvel_loc[3];
+        quat_rotate_s(tq, root + 7, vel_loc, 1);
+        quat_rotate_s(tq, root + 10, angvel_loc, 1);
+        float roll, yaw;
+        euler_roll_yaw(tq, &roll, &yaw);
+        float walk_target_angle = atan2f(p->targets[2] - root[2], p->targets[0] - root[0]);
+        float angle_to_target = walk_target_angle - yaw;
+        if (humanoid) {
+            roll = normalize_angle(roll);
+            yaw = normalize_angle(yaw);
+            angle_to_target = normalize_angle(angle_to_target);
+        }
+
+        obs[0] = root[2];
+        for (int i = 0; i < 3; ++i) obs[1 + i] = vel_loc[i];
+        for (int i = 0; i < 3; ++i)
+            obs[4 + i] = humanoid ? angvel_loc[i] * p->angular_velocity_scale : angvel_loc[i];
+        obs[7] = yaw; obs[8] = roll; obs[9] = angle_to_target;
+        obs[10] = up_proj; obs[11] = heading_proj;
+        int c = 12;
+        for (int j = 0; j < D; ++j)
+            obs[c + j] = unscale1(ds[2 * j], p->dof_limits_lower[j], p->dof_limits_upper[j]);
+        c += D;
+        for (int j = 0; j < D; ++j) obs[c + j] = ds[2 * j + 1] * p->dof_vel_scale;
+        c += D;
+        if (humanoid) {
+            for (int j = 0; j < D; ++j) obs[c + j] = b->dof_force[e * D + j] * p->contact_force_scale;
+            c += D;
+        }
+        for (int j = 0; j < S; ++j) obs[c + j] = b->sensors[e * S + j] * p->contact_force_scale;
+        c += S;
+        for (int j = 0; j < D; ++j) obs[c + j] = act[j];
+
+        b->potentials[e] = pot;
+        b->prev_potentials[e] = prev_pot;
+        for (int i = 0; i < 3; ++i) {
+            b->up_vec[e * 3 + i] = up_vec[i];
+            b->heading_vec[e * 3 + i] = heading_vec[i];
+        }
+
+        /* compute_*_reward */
+        float heading_reward = (obs[11] > 0.8f) ? p->heading_weight : p->heading_weight * obs[11] / 0.8f;
+        float up_reward = (obs[10] > 0.93f) ? 0.0f + p->up_weight : 0.0f;
+        float tmp[IGX_MAX_DOF];
+        for (int j = 0; j < D; ++j) tmp[j] = act[j] * act[j];
+        float actions_cost = row_sum(tmp, D);
+        float total;
+        float progress_reward = pot - prev_pot;
+        if (!humanoid) {
+            for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * obs[12 + D + j]);
+            float electricity_cost = row_sum(tmp, D);
+            int64_t cnt = 0;
+            for (int j = 0; j < D; ++j) cnt += (obs[12 + j] > 0.99f);
+            total = progress_reward + 0.5f + up_reward + heading_reward
+                  - p->actions_cost_scale * actions_cost - p->energy_cost_scale * electricity_cost
+                  - (float)cnt * p->joints_at_limit_cost_scale;
+        } else {
+            for (int j = 0; j < D; ++j) {
+                float ab = fabsf(obs[12 + j]);
+                float scaled = p->joints_at_limit_cost_scale * (ab - 0.98f) / 0.02f;
+                tmp[j] = ((ab > 0.98f) ? 1.0f : 0.0f) * scaled * ratio[j];
+            }
+            float dof_at_limit_cost = row_sum(tmp, D);
+            for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * obs[12 + D + j]) * ratio[j];
+            float electricity_cost = row_sum(tmp, D);
+            total = progress_reward + 2.0f + up_reward + heading_reward
+                  - p->actions_cost_scale * actions_cost - p->energy_cost_scale * electricity_cost
+                  - dof_at_limit_cost;
+        }
+        if (obs[0] < p->termination_height) total = p->death_cost;
+        if (obs[0] < p->termination_height) rst = 1;
+        if ((float)prog >= p->max_episode_length_m1) rst = 1;
+
+        b->rew[e] = total;
+        b->reset[e] = rst;
+        b->progress[e] = prog;
+        if (b->true_objective) b->true_objective[e] = root[7];
+    }
+    return 0;
+}
+
+int orc_ant_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n)
+{
+    return loco_step(p, b, n, 0);
+}
+
+int orc_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n)
+{
+    return loco_step(p, b, n, 1);
+}
