@@ -1,0 +1,116 @@
+"""Loader and thin call layer for libigx.so (the HIP kernels behind the C ABI).
+
+There is no fallback: if the shared library is missing, or a tensor is not a
+contiguous device tensor of the documented dtype, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libigx.so")
+_lib = None
+
+# every symbol include/igx.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_STEP_SIG = (C.c_int, [_P, _P, C.c_int64, _P])
+SYMBOLS = {
+    "igx_version": (C.c_int, []),
+    "igx_last_error_string": (C.c_char_p, []),
+    "igx_cartpole_step": _STEP_SIG,
+    "igx_ant_step": _STEP_SIG,
+    "igx_humanoid_step": _STEP_SIG,
+}
+
+
+class IgxError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libigx error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib():
+    """Load libigx.so once; raise ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `make -C isaacgym_amd/csrc` (or __graft_entry__.build()); "
+                "isaacgym_amd has no CPU fallback" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IgxError(rc, lib().igx_last_error_string().decode("utf-8", "replace"))
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def tensor_ptr(t, dtype=None):
+    """Raw device address of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor, got %r" % type(t))
+    if not t.is_cuda:
+        raise ValueError("libigx works on device tensors only (got a %s tensor)" % t.device)
+    if not t.is_contiguous():
+        raise ValueError("libigx needs contiguous tensors; pass the base tensor, not a strided view")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("expected dtype %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+_I64_FIELDS = {"reset", "progress", "randomize", "reset_goal", "terminate", "motion_ids", "frame_idx0",
+               "frame_idx1", "object_indices", "goal_object_indices", "env_ids"}
+_F64_FIELDS = {"motion_times"}
+
+
+def _ptr_checked(name):
+    def f(t):
+        want = torch.int64 if name in _I64_FIELDS else torch.float64 if name in _F64_FIELDS else torch.float32
+        return tensor_ptr(t, want)
+    return f
+
+
+def make_buffers(cls, tensors):
+    """Build a *Buffers struct from name->tensor; checks device/dtype/contiguity
+    and that every tensor lives on the same device."""
+    dev = None
+    for k, t in tensors.items():
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("buffer %r is on %s, others on %s" % (k, t.device, dev))
+    names = {n for n, _ in cls._fields_}
+    for k in tensors:
+        if k not in names:
+            raise KeyError("%s has no buffer named %r" % (cls.__name__, k))
+    b = cls()
+    for n in names:
+        t = tensors.get(n)
+        setattr(b, n, None if t is None else _ptr_checked(n)(t))
+    return b, dev
+
+
+def call_step(symbol, params, bufcls, tensors, n):
+    b, dev = make_buffers(bufcls, tensors)
+    if dev is None:
+        raise ValueError("no device buffers given")
+    with torch.cuda.device(dev):
+        rc = getattr(lib(), symbol)(C.byref(params), C.byref(b), C.c_int64(n), current_stream(dev))
+    check(rc)

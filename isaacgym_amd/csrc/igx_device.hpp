@@ -1,0 +1,154 @@
+// Device-side math shared by all libigx kernels (gfx950).
+//
+// Numerics contract: the reference runs every ATen op as its own CPU kernel,
+// so every intermediate is rounded to fp32 once per operation.  These helpers
+// therefore use one IEEE operation per source operation (build with
+// -ffp-contract=off; '/' and sqrtf are correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt) and an explicit fused multiply-add
+// only where the ATen CPU kernel fuses (torch.cross, vector norm).
+// Quaternions are xyzw.  File:line citations are into
+// IsaacGymEnvs/isaacgymenvs/utils/torch_jit_utils.py of the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace igx {
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// :41-62 quat_mul, 8-multiply form
+__device__ __forceinline__ f4 quat_mul(f4 a, f4 b)
+{
+    float ww = (a.z + a.x) * (b.x + b.y);
+    float yy = (a.w - a.y) * (b.w + b.z);
+    float zz = (a.w + a.y) * (b.w - b.z);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (a.z - a.x) * (b.x - b.y));
+    f4 o;
+    o.w = qq - ww + (a.z - a.y) * (b.y - b.z);
+    o.x = qq - xx + (a.x + a.w) * (b.x + b.w);
+    o.y = qq - yy + (a.w - a.x) * (b.y + b.z);
+    o.z = qq - zz + (a.z + a.y) * (b.w - b.x);
+    return o;
+}
+
+// :106-110
+__device__ __forceinline__ f4 quat_conjugate(f4 a) { return f4{-a.x, -a.y, -a.z, a.w}; }
+
+// torch.cross on CPU: one fused multiply-add per component
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return f3{fma_rn(a.y, b.z, -(a.z * b.y)), fma_rn(a.z, b.x, -(a.x * b.z)), fma_rn(a.x, b.y, -(a.y * b.x))};
+}
+
+// torch.bmm([N,1,3],[N,3,1]) on CPU: unfused dot accumulated onto +0
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return ((0.0f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
+
+// torch.norm(p=2, dim=-1) of a 3-vector on CPU
+__device__ __forceinline__ float norm3(f3 v)
+{
+    float acc = v.x * v.x;
+    acc = fma_rn(v.y, v.y, acc);
+    acc = fma_rn(v.z, v.z, acc);
+    return sqrtf(acc);
+}
+
+__device__ __forceinline__ float norm4(f4 v)
+{
+    float acc = v.x * v.x;
+    acc = fma_rn(v.y, v.y, acc);
+    acc = fma_rn(v.z, v.z, acc);
+    acc = fma_rn(v.w, v.w, acc);
+    return sqrtf(acc);
+}
+
+// :65-67 normalize
+__device__ __forceinline__ f3 normalize3(f3 v)
+{
+    float n = norm3(v);
+    n = (n < 1e-9f) ? 1e-9f : n;
+    return f3{v.x / n, v.y / n, v.z / n};
+}
+
+// :80-90 quat_rotate / :411-421 my_quat_rotate (INVERSE=false),
+// :93-103 quat_rotate_inverse (INVERSE=true)
+template <bool INVERSE>
+__device__ __forceinline__ f3 quat_rotate(f4 q, f3 v)
+{
+    f3 qv{q.x, q.y, q.z};
+    float s = 2.0f * (q.w * q.w) - 1.0f;
+    f3 cr = cross3(qv, v);
+    float d = dot3(qv, v);
+    f3 a{v.x * s, v.y * s, v.z * s};
+    f3 b{cr.x * q.w * 2.0f, cr.y * q.w * 2.0f, cr.z * q.w * 2.0f};
+    f3 c{qv.x * d * 2.0f, qv.y * d * 2.0f, qv.z * d * 2.0f};
+    if (INVERSE) return f3{a.x - b.x + c.x, a.y - b.y + c.y, a.z - b.z + c.z};
+    return f3{a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z};
+}
+
+#define IGX_TWO_PI_F 6.2831855f
+
+// torch.remainder(x, float32(2*pi))
+__device__ __forceinline__ float remainder_2pi(float x)
+{
+    float m = fmodf(x, IGX_TWO_PI_F);
+    if (m != 0.0f && m < 0.0f) m += IGX_TWO_PI_F;
+    return m;
+}
+
+// :126-128
+__device__ __forceinline__ float normalize_angle(float x) { return atan2f(sinf(x), cosf(x)); }
+
+// :175-195 get_euler_xyz (roll and yaw; pitch is unused on this path)
+__device__ __forceinline__ void euler_roll_yaw(f4 q, float &roll, float &yaw)
+{
+    float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
+    float cosr_cosp = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+    float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+    float cosy_cosp = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
+    roll = remainder_2pi(atan2f(sinr_cosp, cosr_cosp));
+    yaw = remainder_2pi(atan2f(siny_cosp, cosy_cosp));
+}
+
+// :239-241 unscale
+__device__ __forceinline__ float unscale(float x, float lo, float hi) { return (2.0f * x - hi - lo) / (hi - lo); }
+// :234-236 scale
+__device__ __forceinline__ float scale(float x, float lo, float hi) { return 0.5f * (x + 1.0f) * (hi - lo) + lo; }
+// :228-230 tensor_clamp
+__device__ __forceinline__ float tensor_clamp(float t, float lo, float hi) { return fmaxf(fminf(t, hi), lo); }
+
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11).  Used for the
+// reset draws when the caller supplies no pre-drawn uniforms.  Counter layout:
+// (env lo, env hi, offset lo, offset hi[23:0] << 8 | block), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// Uniforms 4*blk .. 4*blk+3 of environment `env` at step `offset`, in [0,1).
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t offset, int64_t env, int blk, float (&u)[4])
+{
+    uint32_t c[4];
+    c[0] = (uint32_t)(uint64_t)env;
+    c[1] = (uint32_t)((uint64_t)env >> 32);
+    c[2] = (uint32_t)offset;
+    c[3] = (((uint32_t)(offset >> 32) & 0xFFFFFFu) << 8) | (uint32_t)blk;
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
+}
+
+}  // namespace igx

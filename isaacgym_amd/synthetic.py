@@ -1,0 +1,120 @@
+"""Seeded synthetic state tensors standing in for the physics engine.
+
+The closed-source simulator is out of scope; parity tests and the benchmark
+feed the step kernels with tensors drawn here (distributions chosen so that
+every branch is exercised: ~0.5 % of envs below the termination height, a few
+% of joints beyond the soft limits, ~0.1 % of envs timing out per step).
+"""
+import math
+
+import torch
+
+from . import _abi
+
+ANT = dict(num_dof=8, num_sensor_floats=24, num_obs=60, z_mean=0.55, z_std=0.1, humanoid=False,
+           dt=0.0166, dof_vel_scale=0.2, contact_force_scale=0.1, angular_velocity_scale=0.1,
+           up_weight=0.1, heading_weight=0.5, actions_cost_scale=0.005, energy_cost_scale=0.05,
+           joints_at_limit_cost_scale=0.1, termination_height=0.31, death_cost=-2.0,
+           max_episode_length=1000)
+HUMANOID = dict(num_dof=21, num_sensor_floats=12, num_obs=108, z_mean=1.34, z_std=0.3, humanoid=True,
+                dt=0.0166, dof_vel_scale=0.1, contact_force_scale=0.01, angular_velocity_scale=0.25,
+                up_weight=0.1, heading_weight=0.5, actions_cost_scale=0.01, energy_cost_scale=0.05,
+                joints_at_limit_cost_scale=0.25, termination_height=0.8, death_cost=-1.0,
+                max_episode_length=1000)
+
+
+def loco_limits(D):
+    lo = [-1.0 - 0.01 * j for j in range(D)]
+    hi = [1.0 + 0.02 * j for j in range(D)]
+    return lo, hi
+
+
+def loco_params(spec, seed=0, rng_offset=0):
+    D = spec["num_dof"]
+    lo, hi = loco_limits(D)
+    p = _abi.LocoParams(
+        num_dof=D, num_sensor_floats=spec["num_sensor_floats"], dt=spec["dt"],
+        dof_vel_scale=spec["dof_vel_scale"], contact_force_scale=spec["contact_force_scale"],
+        angular_velocity_scale=spec["angular_velocity_scale"], up_weight=spec["up_weight"],
+        heading_weight=spec["heading_weight"], actions_cost_scale=spec["actions_cost_scale"],
+        energy_cost_scale=spec["energy_cost_scale"],
+        joints_at_limit_cost_scale=spec["joints_at_limit_cost_scale"],
+        termination_height=spec["termination_height"], death_cost=spec["death_cost"],
+        max_episode_length_m1=float(spec["max_episode_length"] - 1),
+        targets=[1000.0, 0.0, 0.0], inv_start_rot=[-0.0, -0.0, -0.0, 1.0],
+        basis_vec0=[1.0, 0.0, 0.0], basis_vec1=[0.0, 0.0, 1.0],
+        dof_limits_lower=lo, dof_limits_upper=hi, seed=seed, rng_offset=rng_offset)
+    if spec["humanoid"]:
+        efforts = [20.0 + 180.0 * ((7 * j) % D) / D for j in range(D)]
+        p.set("motor_efforts", efforts)
+        p.max_motor_effort = max(efforts)
+    return p
+
+
+def _quats(n, gen, device):
+    q = torch.randn(n, 4, generator=gen, device=device)
+    small = torch.randn(n, 4, generator=gen, device=device) * 1e-3
+    small[:, 3] = 1.0
+    pick = torch.rand(n, generator=gen, device=device) < 0.5
+    q = torch.where(pick.unsqueeze(-1), q, small)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def loco_state(spec, n, seed, device, with_rand=False):
+    """Returns the name->tensor dict of igx_loco_buffers for n environments."""
+    D, S = spec["num_dof"], spec["num_sensor_floats"]
+    gen = torch.Generator(device=device).manual_seed(seed)
+    lo, hi = loco_limits(D)
+    lo = torch.tensor(lo, device=device)
+    hi = torch.tensor(hi, device=device)
+    root = torch.empty(n, 13, device=device)
+    root[:, 0:3] = torch.randn(n, 3, generator=gen, device=device) * 0.1
+    root[:, 2] = spec["z_mean"] + torch.randn(n, generator=gen, device=device) * spec["z_std"]
+    root[:, 3:7] = _quats(n, gen, device)
+    root[:, 7:13] = torch.randn(n, 6, generator=gen, device=device)
+    dof_state = torch.empty(n, D, 2, device=device)
+    u = torch.rand(n, D, generator=gen, device=device) * 1.04 - 0.02
+    dof_state[..., 0] = lo + (hi - lo) * u
+    dof_state[..., 1] = torch.randn(n, D, generator=gen, device=device)
+    init_root = torch.zeros(n, 13, device=device)
+    init_root[:, 0:2] = torch.randn(n, 2, generator=gen, device=device) * 0.05
+    init_root[:, 2] = spec["z_mean"]
+    init_root[:, 6] = 1.0
+    t = dict(
+        root_states=root, dof_state=dof_state,
+        sensors=torch.randn(n, S, generator=gen, device=device) * 10.0,
+        actions=torch.rand(n, D, generator=gen, device=device) * 2.0 - 1.0,
+        initial_root_states=init_root,
+        initial_dof_pos=torch.zeros(n, D, device=device),
+        obs=torch.zeros(n, spec["num_obs"], device=device),
+        potentials=torch.full((n,), -1000.0 / spec["dt"], device=device),
+        prev_potentials=torch.full((n,), -1000.0 / spec["dt"], device=device),
+        up_vec=torch.zeros(n, 3, device=device), heading_vec=torch.zeros(n, 3, device=device),
+        rew=torch.zeros(n, device=device),
+        reset=(torch.rand(n, generator=gen, device=device) < 0.01).to(torch.int64),
+        progress=torch.randint(0, spec["max_episode_length"], (n,), generator=gen, device=device),
+        randomize=torch.zeros(n, dtype=torch.int64, device=device),
+    )
+    if spec["humanoid"]:
+        t["dof_force"] = torch.randn(n, D, generator=gen, device=device) * 30.0
+    if with_rand:
+        t["rand"] = torch.rand(n, 2 * D, generator=gen, device=device)
+    return t
+
+
+def cartpole_state(n, seed, device, with_rand=False):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    ds = torch.empty(n, 2, 2, device=device)
+    ds[:, 0, 0] = (torch.rand(n, generator=gen, device=device) * 2 - 1) * 3.5
+    ds[:, 1, 0] = (torch.rand(n, generator=gen, device=device) * 2 - 1) * 2.0
+    ds[:, :, 1] = torch.randn(n, 2, generator=gen, device=device)
+    t = dict(dof_state=ds, obs=torch.zeros(n, 4, device=device), rew=torch.zeros(n, device=device),
+             reset=(torch.rand(n, generator=gen, device=device) < 0.05).to(torch.int64),
+             progress=torch.randint(0, 500, (n,), generator=gen, device=device))
+    if with_rand:
+        t["rand"] = torch.rand(n, 4, generator=gen, device=device)
+    return t
+
+
+def cartpole_params(seed=0, rng_offset=0):
+    return _abi.CartpoleParams(reset_dist=3.0, max_episode_length_m1=499.0, seed=seed, rng_offset=rng_offset)

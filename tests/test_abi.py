@@ -1,0 +1,68 @@
+"""The C-ABI library loads and exports every symbol include/igx.h declares
+(no compute calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from isaacgym_amd import _abi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "igx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(igx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = _declared_symbols()
+    assert "igx_ant_step" in names and "igx_last_error_string" in names
+    for n in names:
+        assert hasattr(lib, n), "libigx.so does not export %s" % n
+        assert n in _lib.SYMBOLS, "isaacgym_amd._lib.SYMBOLS lacks %s" % n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_error_string():
+    lib = _lib.lib()
+    assert lib.igx_version() >= 100
+    assert isinstance(lib.igx_last_error_string(), bytes)
+
+
+def test_struct_sizes_match_header():
+    # sizes computed from the header by the C compiler
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "igx.h"
+int main(void){
+  printf("CartpoleParams %zu\n", sizeof(igx_cartpole_params));
+  printf("CartpoleBuffers %zu\n", sizeof(igx_cartpole_buffers));
+  printf("LocoParams %zu\n", sizeof(igx_loco_params));
+  printf("LocoBuffers %zu\n", sizeof(igx_loco_buffers));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode()
+    for line in out.strip().splitlines():
+        name, size = line.split()
+        assert ctypes.sizeof(getattr(_abi, name)) == int(size), name
+
+
+def test_null_arguments_are_rejected_without_a_gpu():
+    lib = _lib.lib()
+    rc = lib.igx_ant_step(None, None, 16, None)
+    assert rc == _abi.IGX_E_NULL
+    assert b"NULL" in lib.igx_last_error_string()
+    p = _abi.LocoParams(num_dof=8, num_sensor_floats=24)
+    b = _abi.LocoBuffers()
+    assert lib.igx_ant_step(ctypes.byref(p), ctypes.byref(b), -1, None) == _abi.IGX_E_SIZE
+    assert lib.igx_ant_step(ctypes.byref(p), ctypes.byref(b), 16, None) == _abi.IGX_E_NULL
+    assert lib.igx_humanoid_step(ctypes.byref(p), ctypes.byref(b), 16, None) == _abi.IGX_E_PARAM

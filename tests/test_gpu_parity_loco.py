@@ -1,0 +1,158 @@
+"""GPU parity: HIP kernels (through the C ABI) against the golden vectors and
+against the CPU checker on seeded synthetic inputs.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from isaacgym_amd import ops, synthetic
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_cartpole_golden():
+    g = H.load_golden("cartpole")
+    m = g["meta"]
+    N, T = m["N"], m["T"]
+    p = H.cartpole_params(m)
+    reset, progress = _to_dev(g["reset0"]), _to_dev(g["progress0"])
+    for t in range(T):
+        ds = _to_dev(g["in_dof_state"][t])
+        obs = torch.zeros(N, 4, device=DEV)
+        rew = torch.zeros(N, device=DEV)
+        ops.cartpole_step(p, dict(dof_state=ds, rand=_to_dev(g["rand"][t]), obs=obs, rew=rew, reset=reset,
+                                  progress=progress), N)
+        assert np.array_equal(reset.cpu().numpy(), g["reset"][t])
+        assert np.array_equal(progress.cpu().numpy(), g["progress"][t])
+        assert H.bit_equal_fraction(ds.cpu().numpy(), g["out_dof_state"][t]) == 1.0
+        assert H.bit_equal_fraction(obs.cpu().numpy(), g["obs"][t]) == 1.0
+        assert H.bit_equal_fraction(rew.cpu().numpy(), g["rew"][t]) == 1.0
+
+
+@pytest.mark.parametrize("n,with_rand", [(0, False), (1, True), (255, True), (4096, False), (1000003, False)])
+def test_cartpole_vs_oracle(n, with_rand):
+    p = synthetic.cartpole_params(seed=77, rng_offset=5)
+    t = synthetic.cartpole_state(n, 3, DEV, with_rand)
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    ops.cartpole_step(p, t, n)
+    torch.cuda.synchronize()
+    if n == 0:
+        return
+    oracle.cartpole_step(p, ref, n)
+    for k in ("reset", "progress"):
+        assert np.array_equal(t[k].cpu().numpy(), ref[k]), k
+    for k in ("dof_state", "obs", "rew"):
+        assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k
+
+
+def _golden_loco(name, step, nobs, humanoid):
+    g = H.load_golden(name)
+    m = g["meta"]
+    N, T = m["N"], m["T"]
+    p = H.loco_params(m, g)
+    reset, progress, pot = _to_dev(g["reset0"]), _to_dev(g["progress0"]), _to_dev(g["potentials0"])
+    randomize = torch.zeros(N, dtype=torch.int64, device=DEV)
+    init_root, init_dof = _to_dev(g["initial_root_states"]), _to_dev(g["initial_dof_pos"])
+    nonangle = [c for c in range(nobs) if c not in H.LOCO_ANGLE_COLS]
+    ang = list(H.LOCO_ANGLE_COLS)
+    for t in range(T):
+        ds = _to_dev(g["in_dof_state"][t])
+        out = dict(obs=torch.zeros(N, nobs, device=DEV), prev_potentials=torch.zeros(N, device=DEV),
+                   up_vec=torch.zeros(N, 3, device=DEV), heading_vec=torch.zeros(N, 3, device=DEV),
+                   rew=torch.zeros(N, device=DEV))
+        bufs = dict(root_states=_to_dev(g["in_root"][t]), dof_state=ds, sensors=_to_dev(g["in_sensors"][t]),
+                    actions=_to_dev(g["in_actions"][t]), initial_root_states=init_root,
+                    initial_dof_pos=init_dof, rand=_to_dev(g["rand"][t]), potentials=pot, reset=reset,
+                    progress=progress, randomize=randomize, **out)
+        if humanoid:
+            bufs["dof_force"] = _to_dev(g["in_dof_force"][t])
+        else:
+            bufs["true_objective"] = torch.zeros(N, device=DEV)
+        step(p, bufs, N)
+        assert np.array_equal(reset.cpu().numpy(), g["reset"][t]), "reset step %d" % t
+        assert np.array_equal(progress.cpu().numpy(), g["progress"][t]), "progress step %d" % t
+        assert np.array_equal(randomize.cpu().numpy(), g["randomize"][t])
+        obs = out["obs"].cpu().numpy()
+        # tolerance bar of the task statement (1e-5 relative, natural scale) ...
+        H.assert_close(obs[:, nonangle], g["obs"][t][:, nonangle], what="obs step %d" % t)
+        H.assert_angle_close(obs[:, ang], g["obs"][t][:, ang], what="obs angles step %d" % t)
+        H.assert_close(out["rew"].cpu().numpy(), g["rew"][t], what="rew step %d" % t)
+        # ... and the stronger property the exact arithmetic model gives:
+        for key, arr in (("out_dof_state", ds), ("potentials", pot), ("prev_potentials", out["prev_potentials"]),
+                         ("up_vec", out["up_vec"]), ("heading_vec", out["heading_vec"]), ("rew", out["rew"])):
+            f = H.bit_equal_fraction(arr.cpu().numpy(), g[key][t])
+            assert f == 1.0, "%s step %d bit-equal fraction %f" % (key, t, f)
+        assert H.bit_equal_fraction(obs[:, nonangle], g["obs"][t][:, nonangle]) == 1.0
+        if not humanoid:
+            assert H.bit_equal_fraction(bufs["true_objective"].cpu().numpy(), g["true_objective"][t]) == 1.0
+
+
+def test_ant_golden():
+    _golden_loco("ant", ops.ant_step, 60, False)
+
+
+def test_humanoid_golden():
+    _golden_loco("humanoid", ops.humanoid_step, 108, True)
+
+
+def _vs_oracle(spec, step, ostep, n, with_rand, steps=2):
+    p = synthetic.loco_params(spec, seed=1234, rng_offset=9)
+    t = synthetic.loco_state(spec, n, 11, DEV, with_rand)
+    if not spec["humanoid"]:
+        t["true_objective"] = torch.zeros(n, device=DEV)
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    nobs = spec["num_obs"]
+    nonangle = [c for c in range(nobs) if c not in H.LOCO_ANGLE_COLS]
+    ang = list(H.LOCO_ANGLE_COLS)
+    for s in range(steps):
+        p.rng_offset = 9 + s
+        step(p, t, n)
+        torch.cuda.synchronize()
+        if n == 0:
+            continue
+        ostep(p, ref, n)
+        for k in ("reset", "progress", "randomize"):
+            assert np.array_equal(t[k].cpu().numpy(), ref[k]), "%s step %d" % (k, s)
+        obs = t["obs"].cpu().numpy()
+        assert H.bit_equal_fraction(obs[:, nonangle], ref["obs"][:, nonangle]) == 1.0, "obs step %d" % s
+        H.assert_angle_close(obs[:, ang], ref["obs"][:, ang], what="angles step %d" % s)
+        for k in ("dof_state", "potentials", "prev_potentials", "up_vec", "heading_vec", "rew"):
+            assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, "%s step %d" % (k, s)
+        # next step: new "physics" state on both sides
+        nxt = synthetic.loco_state(spec, n, 100 + s, DEV, with_rand)
+        for k in ("root_states", "dof_state", "sensors", "actions") + (("dof_force",) if spec["humanoid"] else ()):
+            t[k].copy_(nxt[k])
+            ref[k][...] = nxt[k].cpu().numpy()
+
+
+@pytest.mark.parametrize("n,with_rand", [(0, False), (1, True), (63, True), (257, False), (100003, True),
+                                         (1 << 20, False)])
+def test_ant_vs_oracle(n, with_rand):
+    _vs_oracle(synthetic.ANT, ops.ant_step, oracle.ant_step, n, with_rand)
+
+
+@pytest.mark.parametrize("n,with_rand", [(1, True), (129, False), (50001, True), (1 << 19, False)])
+def test_humanoid_vs_oracle(n, with_rand):
+    _vs_oracle(synthetic.HUMANOID, ops.humanoid_step, oracle.humanoid_step, n, with_rand)
+
+
+def test_rejects_bad_arguments():
+    from isaacgym_amd._lib import IgxError
+    p = synthetic.loco_params(synthetic.ANT)
+    t = synthetic.loco_state(synthetic.ANT, 64, 0, DEV)
+    bad = dict(t)
+    bad["obs"] = None
+    with pytest.raises(IgxError):
+        ops.ant_step(p, bad, 64)
+    with pytest.raises(IgxError):
+        ops.humanoid_step(p, t, 64)  # wrong num_dof for this entry point
+    with pytest.raises(ValueError):
+        ops.ant_step(p, dict(t, obs=t["obs"].cpu()), 64)
+    with pytest.raises(ValueError):
+        ops.ant_step(p, dict(t, dof_state=t["dof_state"][..., 0]), 64)  # strided view
