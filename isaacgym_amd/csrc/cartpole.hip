@@ -57,6 +57,7 @@ extern "C" int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpol
     if (!p || !b) return igx::fail(IGX_E_NULL, "igx_cartpole_step: params/buffers struct is NULL");
     if (n_envs < 0 || n_envs > ((int64_t)1 << 38))
         return igx::fail(IGX_E_SIZE, "igx_cartpole_step: n_envs %lld out of range", (long long)n_envs);
+    if (n_envs == 0) return IGX_OK;  // empty batch: nothing to validate or launch
     IGX_REQUIRE_PTR(b->dof_state, "dof_state");
     IGX_REQUIRE_PTR(b->obs, "obs");
     IGX_REQUIRE_PTR(b->rew, "rew");
@@ -65,7 +66,6 @@ extern "C" int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpol
     IGX_REQUIRE_ALIGNED(b->dof_state, "dof_state");
     IGX_REQUIRE_ALIGNED(b->obs, "obs");
     if (b->rand) IGX_REQUIRE_ALIGNED(b->rand, "rand");
-    if (n_envs == 0) return IGX_OK;
     const int64_t blocks = (n_envs + 255) / 256;
     hipLaunchKernelGGL(igx::cartpole_step_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *p, *b, n_envs);

@@ -381,6 +381,7 @@ static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64
     if (p->num_dof != D || p->num_sensor_floats != S)
         return fail(IGX_E_PARAM, "%s: expects num_dof=%d num_sensor_floats=%d, got %d/%d", who, D, S, p->num_dof,
                     p->num_sensor_floats);
+    if (n == 0) return IGX_OK;  // empty batch: pointers may legitimately be NULL
     const struct { const void *ptr; const char *name; bool vec; } req[] = {
         {b->root_states, "root_states", true}, {b->dof_state, "dof_state", true},
         {b->sensors, "sensors", true}, {b->actions, "actions", true},
