@@ -11,7 +11,8 @@ import torch
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libigx.so")
+# IGX_LIB overrides the library path (used to A/B differently tuned builds)
+LIB_PATH = os.environ.get("IGX_LIB") or os.path.join(_HERE, "libigx.so")
 _lib = None
 
 # every symbol include/igx.h declares: (name, restype, argtypes)

@@ -91,12 +91,12 @@ __device__ __forceinline__ f3 quat_rotate(f4 q, f3 v)
 
 #define IGX_TWO_PI_F 6.2831855f
 
-// torch.remainder(x, float32(2*pi))
+// torch.remainder(x, float32(2*pi)) for an x that came out of atan2: |x| <= pi,
+// so fmod(x, 2*pi) is x itself and only the sign fix-up of remainder is left
+// (-0.0 stays -0.0, NaN stays NaN, exactly as fmod-then-fix-up gives)
 __device__ __forceinline__ float remainder_2pi(float x)
 {
-    float m = fmodf(x, IGX_TWO_PI_F);
-    if (m != 0.0f && m < 0.0f) m += IGX_TWO_PI_F;
-    return m;
+    return (x < 0.0f) ? x + IGX_TWO_PI_F : x;
 }
 
 // :126-128

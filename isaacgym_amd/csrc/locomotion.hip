@@ -1,17 +1,28 @@
 // Fused post_physics_step for the Ant and Humanoid locomotion tasks.
 //
-// One workgroup owns a tile of TILE consecutive environments.  The
-// observation rows of the tile live in LDS while they are assembled:
-//   phase 1  all lanes stream the tile's AoS inputs with coalesced 16-byte
-//            loads and drop the pass-through / scaled columns (dof position and
-//            velocity, dof force, sensors, actions) straight into the LDS rows;
-//            root-state rows are parked in LDS unchanged;
-//   phase 2  one lane per environment reads its root row, does the reset
-//            bookkeeping and the quaternion math in registers, writes the 12
-//            computed columns, and evaluates the reward from its own LDS row;
-//   phase 3  all lanes write the finished rows to obs with coalesced 16-byte
-//            stores.
-// Every input byte is read once and every output byte written once.
+// Work decomposition: one wavefront (a 64-thread workgroup) owns one tile of
+// 64 consecutive environments; the grid has one workgroup per tile (measured
+// on MI355X: many small one-shot workgroups stream this multi-array pattern
+// faster than persistent waves with a register prefetch).  Per tile:
+//   load     the tile's AoS inputs arrive in registers through coalesced
+//            16-byte non-temporal loads (each lane: consecutive 16-byte chunks
+//            of the tile's contiguous slice of every input array);
+//   root     the 13-float root-state rows are transposed through LDS so that
+//            lane i holds environment i's row in registers;
+//   stage    pass-through / scaled columns (dof position and velocity, dof
+//            force, sensors, actions) go straight from the load registers to
+//            their final column of the LDS image of the 64 observation rows;
+//   reset    environments whose reset flag is set are re-initialised one at a
+//            time by the whole wave (lane j draws and writes joint j);
+//   per-env  lane i: quaternion math in registers, the 12 computed columns
+//            into its LDS row, reward from its own row, per-env scalars
+//            straight to global memory;
+//   drain    the finished rows (then the up / heading vectors) leave LDS as
+//            whole contiguous lines with 16-byte non-temporal stores.
+// Every input byte is read once and every output byte written once; observation
+// rows are only ever written as full contiguous lines (partial-row stores run
+// 2-3x slower on this memory system).  Lanes of the wave exchange data through
+// LDS without a workgroup barrier: a wave's LDS operations execute in order.
 //
 // Reference: tasks/ant.py:376-386, :339-366, :463-497, :414-460 and
 // tasks/humanoid.py:398-407, :360-390, :489-524, :434-486
@@ -21,124 +32,123 @@
 
 namespace igx {
 
+constexpr int WAVE = 64;
+// native vectors: copies of these are real vector loads / stores (a struct
+// copy would become a memcpy through a private-memory temporary)
+using v4f = float __attribute__((ext_vector_type(4)));
+using v2f = float __attribute__((ext_vector_type(2)));
+
+// Streaming (non-temporal) global accesses: every byte of this path is touched
+// exactly once per step, so nothing is worth keeping in L2; on MI355X the nt
+// forms stream ~20 % faster than default-policy loads / stores here.
+template <class T>
+__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+template <class T>
+__device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+
 template <int D, int S, bool HUM>
 struct LocoLayout {
     static constexpr int C_POS = 12;
     static constexpr int C_VEL = 12 + D;
-    static constexpr int C_FORCE = 12 + 2 * D;                 // Humanoid only
+    static constexpr int C_FORCE = 12 + 2 * D;  // Humanoid only
     static constexpr int C_SENS = HUM ? 12 + 3 * D : 12 + 2 * D;
     static constexpr int C_ACT = C_SENS + S;
     static constexpr int NOBS = C_ACT + D;
+    // 16-byte chunks per full tile of each input array, and load rounds per lane
+    static constexpr int ROOT4 = WAVE * 13 / 4;
+    static constexpr int SENS4 = WAVE * S / 4;
+    static constexpr int ACT4 = WAVE * D / 4;
+    static constexpr int DOF4 = WAVE * D * 2 / 4;
+    static constexpr int IT_ROOT = (ROOT4 + WAVE - 1) / WAVE;
+    static constexpr int IT_SENS = (SENS4 + WAVE - 1) / WAVE;
+    static constexpr int IT_ACT = (ACT4 + WAVE - 1) / WAVE;
+    static constexpr int IT_DOF = (DOF4 + WAVE - 1) / WAVE;
 };
 
-
-// Calls f(k) for k = tid, tid+TILE, ... < n4.  For a full tile the trip count
-// is a compile-time constant so the loop unrolls and all loads issue together.
-template <int TILE, bool FULL, int N4_FULL, class F>
-__device__ __forceinline__ void for_each_chunk(int n4, int tid, F f)
+// Compiler-level ordering point for the wave-synchronous LDS exchange.
+__device__ __forceinline__ void wave_sync()
 {
-    if constexpr (FULL) {
-        constexpr int ITERS = (N4_FULL + TILE - 1) / TILE;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N4, int ITERS>
+__device__ __forceinline__ void load_chunks(const float *__restrict__ g, v4f (&v)[ITERS], int lane)
+{
+    const v4f *g4 = reinterpret_cast<const v4f *>(g);
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int k = tid + it * TILE;
-            if ((it + 1) * TILE <= N4_FULL || k < N4_FULL) f(k);
-        }
-    } else {
-        for (int k = tid; k < n4; k += TILE) f(k);
+    for (int it = 0; it < ITERS; ++it) {
+        // the last, partly filled round re-reads the final chunk in its idle
+        // lanes (same cache line, no extra traffic) so every load is unconditional
+        int k = lane + it * WAVE;
+        if ((it + 1) * WAVE > N4) k = (k < N4) ? k : N4 - 1;
+        v[it] = ld_stream(g4 + k);
     }
 }
 
-// Stage rows of ROW floats (global, contiguous over the tile) into columns
-// C0..C0+ROW-1 of the LDS observation rows, optionally scaled.
-template <int ROW, int C0, int NOBS, int TILE, bool FULL, bool SCALE>
-__device__ __forceinline__ void stage_rows(const float *__restrict__ g, float *s_tile, int nvalid, float scl, int tid)
+// Rows of ROW floats -> columns C0.. of the LDS observation rows (optionally scaled).
+template <int ROW, int C0, int NOBS, bool SCALE, int ITERS>
+__device__ __forceinline__ void stage_rows(const v4f (&v)[ITERS], float *s_tile, float scl, int lane)
 {
-    const int count = FULL ? TILE * ROW : nvalid * ROW;
-    const int n4 = count >> 2;
-    const float4 *g4 = reinterpret_cast<const float4 *>(g);
-    if constexpr (ROW % 4 == 0 && C0 % 4 == 0 && NOBS % 4 == 0) {
-        constexpr int R4 = ROW / 4;
-        for_each_chunk<TILE, FULL, TILE * ROW / 4>(n4, tid, [&](int k) {
-            float4 v = g4[k];
-            if (SCALE) { v.x *= scl; v.y *= scl; v.z *= scl; v.w *= scl; }
-            int env = k / R4, part = k - env * R4;
-            *reinterpret_cast<float4 *>(s_tile + env * NOBS + C0 + 4 * part) = v;
-        });
-    } else {
-        for_each_chunk<TILE, FULL, TILE * ROW / 4>(n4, tid, [&](int k) {
-            float4 v = g4[k];
-            float e[4] = {v.x, v.y, v.z, v.w};
+    constexpr int N4 = WAVE * ROW / 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int flat = 4 * k + i;
-                int env = flat / ROW, col = flat - env * ROW;
-                s_tile[env * NOBS + C0 + col] = SCALE ? e[i] * scl : e[i];
+    for (int it = 0; it < ITERS; ++it) {
+        const int k = lane + it * WAVE;
+        if ((it + 1) * WAVE <= N4 || k < N4) {
+            v4f x = v[it];
+            if (SCALE) { x.x *= scl; x.y *= scl; x.z *= scl; x.w *= scl; }
+            if constexpr (ROW % 4 == 0 && C0 % 4 == 0 && NOBS % 4 == 0) {
+                constexpr int R4 = ROW / 4;
+                const int env = k / R4, part = k - env * R4;
+                *reinterpret_cast<v4f *>(s_tile + env * NOBS + C0 + 4 * part) = x;
+            } else {
+                const float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int flat = 4 * k + i;
+                    const int env = flat / ROW, col = flat - env * ROW;
+                    s_tile[env * NOBS + C0 + col] = e[i];
+                }
             }
-        });
-        if (!FULL)
-            for (int flat = (n4 << 2) + tid; flat < count; flat += TILE) {  // <4 trailing floats of a partial tile
-            int env = flat / ROW, col = flat - env * ROW;
-            float v = g[flat];
-            s_tile[env * NOBS + C0 + col] = SCALE ? v * scl : v;
         }
     }
 }
 
-// Stage the interleaved (pos, vel) dof_state rows: position -> unscale ->
-// column C_POS+j, velocity * dof_vel_scale -> column C_VEL+j.
-template <int D, int NOBS, int C_POS, int C_VEL, int TILE, bool FULL>
-__device__ __forceinline__ void stage_dof_state(const float *__restrict__ g, float *s_tile, const float *s_lim,
-                                                int nvalid, float dof_vel_scale, int tid)
+// Interleaved (pos, vel) rows: position -> unscale -> column C_POS+j,
+// velocity * dof_vel_scale -> column C_VEL+j.
+template <int D, int NOBS, int C_POS, int C_VEL, int ITERS>
+__device__ __forceinline__ void stage_dof_state(const v4f (&v)[ITERS], float *s_tile, const float *s_lim,
+                                                float dof_vel_scale, int lane)
 {
-    const int count = FULL ? TILE * D * 2 : nvalid * D * 2;  // floats; always even
-    const int n4 = count >> 2;
-    const float4 *g4 = reinterpret_cast<const float4 *>(g);
-    for_each_chunk<TILE, FULL, TILE * D * 2 / 4>(n4, tid, [&](int k) {
-        float4 v = g4[k];
-        float pos[2] = {v.x, v.z}, vel[2] = {v.y, v.w};
+    constexpr int N4 = WAVE * D * 2 / 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int pr = 2 * k + h;
-            int env = pr / D, j = pr - env * D;
-            float lo = s_lim[j], hi = s_lim[D + j];
-            s_tile[env * NOBS + C_POS + j] = unscale(pos[h], lo, hi);
-            s_tile[env * NOBS + C_VEL + j] = vel[h] * dof_vel_scale;
-        }
-    });
-    if (!FULL) {
-        int pr = (n4 << 1) + tid;  // at most one trailing (pos, vel) pair
-        if (pr * 2 < count) {
-            int env = pr / D, j = pr - env * D;
-            float lo = s_lim[j], hi = s_lim[D + j];
-            s_tile[env * NOBS + C_POS + j] = unscale(g[2 * pr], lo, hi);
-            s_tile[env * NOBS + C_VEL + j] = g[2 * pr + 1] * dof_vel_scale;
+    for (int it = 0; it < ITERS; ++it) {
+        const int k = lane + it * WAVE;
+        if ((it + 1) * WAVE <= N4 || k < N4) {
+            const v4f x = v[it];
+            const float pos[2] = {x.x, x.z}, vel[2] = {x.y, x.w};
+            if constexpr (D % 2 == 0 && C_POS % 2 == 0 && C_VEL % 2 == 0 && NOBS % 2 == 0) {
+                // both dofs of this chunk belong to one environment
+                const int pr = 2 * k;
+                const int env = pr / D, j = pr - env * D;
+                const v2f lo = *reinterpret_cast<const v2f *>(s_lim + j);
+                const v2f hi = *reinterpret_cast<const v2f *>(s_lim + D + j);
+                *reinterpret_cast<v2f *>(s_tile + env * NOBS + C_POS + j) =
+                    v2f{unscale(pos[0], lo.x, hi.x), unscale(pos[1], lo.y, hi.y)};
+                *reinterpret_cast<v2f *>(s_tile + env * NOBS + C_VEL + j) =
+                    v2f{vel[0] * dof_vel_scale, vel[1] * dof_vel_scale};
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pr = 2 * k + h;
+                    const int env = pr / D, j = pr - env * D;
+                    s_tile[env * NOBS + C_POS + j] = unscale(pos[h], s_lim[j], s_lim[D + j]);
+                    s_tile[env * NOBS + C_VEL + j] = vel[h] * dof_vel_scale;
+                }
+            }
         }
     }
-}
-
-// Linear global -> LDS copy (root rows).
-template <int TILE, bool FULL, int ROW>
-__device__ __forceinline__ void copy_in(const float *__restrict__ g, float *s, int nvalid, int tid)
-{
-    const int count = FULL ? TILE * ROW : nvalid * ROW;
-    const int n4 = count >> 2;
-    const float4 *g4 = reinterpret_cast<const float4 *>(g);
-    for_each_chunk<TILE, FULL, TILE * ROW / 4>(n4, tid, [&](int k) { *reinterpret_cast<float4 *>(s + 4 * k) = g4[k]; });
-    if (!FULL)
-        for (int k = (n4 << 2) + tid; k < count; k += TILE) s[k] = g[k];
-}
-
-// Linear LDS -> global copy (finished observation rows).
-template <int TILE, bool FULL, int ROW>
-__device__ __forceinline__ void copy_out(float *__restrict__ g, const float *s, int nvalid, int tid)
-{
-    const int count = FULL ? TILE * ROW : nvalid * ROW;
-    const int n4 = count >> 2;
-    float4 *g4 = reinterpret_cast<float4 *>(g);
-    for_each_chunk<TILE, FULL, TILE * ROW / 4>(n4, tid, [&](int k) { g4[k] = *reinterpret_cast<const float4 *>(s + 4 * k); });
-    if (!FULL)
-        for (int k = (n4 << 2) + tid; k < count; k += TILE) g[k] = s[k];
 }
 
 // torch.sum(dim=-1) over a row of D floats as the ATen CPU kernel orders it:
@@ -183,7 +193,7 @@ __device__ __forceinline__ void read_cols(const float *row, float (&out)[LEN])
     if constexpr (LEN % 4 == 0 && C0 % 4 == 0 && NOBS % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < LEN / 4; ++i) {
-            float4 v = *reinterpret_cast<const float4 *>(row + C0 + 4 * i);
+            const v4f v = *reinterpret_cast<const v4f *>(row + C0 + 4 * i);
             out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
         }
     } else {
@@ -192,192 +202,275 @@ __device__ __forceinline__ void read_cols(const float *row, float (&out)[LEN])
     }
 }
 
-template <int D, int S, bool HUM, int TILE, bool FULL>
-__device__ __forceinline__ void loco_tile(const igx_loco_params &p, const igx_loco_buffers &b, int64_t n, int64_t base,
-                                          int nvalid, float *s_tile, float *s_root, float *s_lim)
+// reset_idx for the environments of this tile whose reset flag is set, one
+// environment at a time with the wave's lanes spread over the joints: lane j
+// draws joint j's position and velocity uniforms, writes the (pos, vel) pair
+// to dof_state and the two derived observation columns to the LDS row.
+template <int D, int S, bool HUM>
+__device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx_loco_buffers &b, int64_t base,
+                                             int lane, uint64_t reset_mask, float *s_tile, const float *s_lim)
+{
+    using L = LocoLayout<D, S, HUM>;
+    while (reset_mask) {
+        const int src = __builtin_ctzll(reset_mask);
+        reset_mask &= reset_mask - 1;
+        const int64_t e = base + src;
+        if (lane < D) {
+            const int j = lane;
+            float up, uv;  // uniforms j (position) and D + j (velocity) of this environment
+            if (b.rand) {
+                up = b.rand[e * (2 * D) + j];
+                uv = b.rand[e * (2 * D) + D + j];
+            } else {
+                float q[4];
+                philox_uniform4(p.seed, p.rng_offset, e, j >> 2, q);
+                const int a = j & 3;
+                up = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
+                philox_uniform4(p.seed, p.rng_offset, e, (D + j) >> 2, q);
+                const int c = (D + j) & 3;
+                uv = c == 0 ? q[0] : c == 1 ? q[1] : c == 2 ? q[2] : q[3];
+            }
+            const float dp = 0.4f * up + (-0.2f);  // torch_rand_float(-0.2, 0.2)
+            const float dv = 0.2f * uv + (-0.1f);  // torch_rand_float(-0.1, 0.1)
+            const float lo = s_lim[j], hi = s_lim[D + j];
+            const float np_ = tensor_clamp(b.initial_dof_pos[e * D + j] + dp, lo, hi);
+            reinterpret_cast<v2f *>(b.dof_state + e * (2 * D))[j] = v2f{np_, dv};
+            float *row = s_tile + src * L::NOBS;
+            row[L::C_POS + j] = unscale(np_, lo, hi);
+            row[L::C_VEL + j] = dv * p.dof_vel_scale;
+        }
+    }
+}
+
+// What lane i computes for environment e from its root row (13 registers) and
+// its LDS observation row.  Returns up_vec / heading_vec for the drain.
+template <int D, int S, bool HUM>
+__device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco_buffers &b, int64_t e,
+                                        const float (&rr)[13], int64_t prog, int64_t rst, int64_t rnd, float pot,
+                                        float *row, const float *s_lim, f3 &up_vec, f3 &heading_vec)
 {
     using L = LocoLayout<D, S, HUM>;
     constexpr int NOBS = L::NOBS;
-    const int tid = threadIdx.x;
+    const f3 pos{rr[0], rr[1], rr[2]};
+    const f4 rot{rr[3], rr[4], rr[5], rr[6]};
+    const f3 lin{rr[7], rr[8], rr[9]};
+    const f3 ang{rr[10], rr[11], rr[12]};
 
-    // ---- phase 1: coalesced loads, pass-through columns into the LDS rows
-    if (tid < 2 * D) s_lim[tid] = (tid < D) ? p.dof_limits_lower[tid] : p.dof_limits_upper[tid - D];
+    prog += 1;
+    if (b.randomize) st_stream(b.randomize + e, rnd + 1);
 
-    const int64_t e = base + tid;
-    const bool live = FULL || tid < nvalid;
-    int64_t prog = 0, rst = 0, rnd = 0;
-    float pot = 0.0f;
-    if (live) {
-        prog = b.progress[e];
-        rst = b.reset[e];
-        pot = b.potentials[e];
-        if (b.randomize) rnd = b.randomize[e];
+    if (rst != 0) {  // reset_idx, per-env scalars (the joints were re-drawn by reset_joints)
+        const float *ir = b.initial_root_states + e * 13;
+        const f3 tt{p.targets[0] - ir[0], p.targets[1] - ir[1], 0.0f};
+        pot = -norm3(tt) / p.dt;
+        prog = 0;
+        rst = 0;
     }
-    copy_in<TILE, FULL, 13>(b.root_states + base * 13, s_root, nvalid, tid);
-    stage_rows<S, L::C_SENS, NOBS, TILE, FULL, true>(b.sensors + base * S, s_tile, nvalid, p.contact_force_scale, tid);
-    stage_rows<D, L::C_ACT, NOBS, TILE, FULL, false>(b.actions + base * D, s_tile, nvalid, 1.0f, tid);
-    if constexpr (HUM)
-        stage_rows<D, L::C_FORCE, NOBS, TILE, FULL, true>(b.dof_force + base * D, s_tile, nvalid, p.contact_force_scale, tid);
-    __syncthreads();  // s_lim visible
-    stage_dof_state<D, NOBS, L::C_POS, L::C_VEL, TILE, FULL>(b.dof_state + base * D * 2, s_tile, s_lim, nvalid,
-                                                            p.dof_vel_scale, tid);
-    __syncthreads();
 
-    // ---- phase 2: one environment per lane
-    if (live) {
-        float *row = s_tile + tid * NOBS;
-        const float *rr = s_root + tid * 13;
-        const f3 pos{rr[0], rr[1], rr[2]};
-        const f4 rot{rr[3], rr[4], rr[5], rr[6]};
-        const f3 lin{rr[7], rr[8], rr[9]};
-        const f3 ang{rr[10], rr[11], rr[12]};
-
-        prog += 1;
-        if (b.randomize) b.randomize[e] = rnd + 1;
-
-        if (rst != 0) {  // reset_idx: new joint state, potentials from the initial root position
-            float *ds = b.dof_state + e * (2 * D);
-            const float *idp = b.initial_dof_pos + e * D;
-            // 2D uniforms: D position draws then D velocity draws
-            constexpr int NU = 2 * D, NBLK = (NU + 3) / 4;
-            float u[NBLK * 4];
-            if (b.rand) {
-#pragma unroll
-                for (int j = 0; j < NU; ++j) u[j] = b.rand[e * NU + j];
-            } else {
-#pragma unroll
-                for (int k = 0; k < NBLK; ++k) {
-                    float q[4];
-                    philox_uniform4(p.seed, p.rng_offset, e, k, q);
-                    u[4 * k] = q[0]; u[4 * k + 1] = q[1]; u[4 * k + 2] = q[2]; u[4 * k + 3] = q[3];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                float dp = 0.4f * u[j] + (-0.2f);      // torch_rand_float(-0.2, 0.2)
-                float dv = 0.2f * u[D + j] + (-0.1f);  // torch_rand_float(-0.1, 0.1)
-                float lo = s_lim[j], hi = s_lim[D + j];
-                float np_ = tensor_clamp(idp[j] + dp, lo, hi);
-                reinterpret_cast<float2 *>(ds)[j] = make_float2(np_, dv);
-                row[L::C_POS + j] = unscale(np_, lo, hi);
-                row[L::C_VEL + j] = dv * p.dof_vel_scale;
-            }
-            const float *ir = b.initial_root_states + e * 13;
-            f3 tt{p.targets[0] - ir[0], p.targets[1] - ir[1], 0.0f};
-            pot = -norm3(tt) / p.dt;
-            prog = 0;
-            rst = 0;
-        }
-
-        // compute_*_observations
-        const f3 to_target{p.targets[0] - pos.x, p.targets[1] - pos.y, 0.0f};
-        const float prev_pot = pot;
-        pot = -norm3(to_target) / p.dt;
-        const f3 target_dirs = normalize3(to_target);
-        const f4 isr{p.inv_start_rot[0], p.inv_start_rot[1], p.inv_start_rot[2], p.inv_start_rot[3]};
-        const f4 tq = quat_mul(rot, isr);
-        const f3 up_vec = quat_rotate<false>(tq, f3{p.basis_vec1[0], p.basis_vec1[1], p.basis_vec1[2]});
-        const f3 heading_vec = quat_rotate<false>(tq, f3{p.basis_vec0[0], p.basis_vec0[1], p.basis_vec0[2]});
-        const float up_proj = up_vec.z;
-        const float heading_proj = dot3(heading_vec, target_dirs);
-        const f3 vel_loc = quat_rotate<true>(tq, lin);
-        f3 angvel_loc = quat_rotate<true>(tq, ang);
-        float roll, yaw;
-        euler_roll_yaw(tq, roll, yaw);
-        float angle_to_target = atan2f(p.targets[2] - pos.z, p.targets[0] - pos.x) - yaw;
-        if constexpr (HUM) {
-            roll = normalize_angle(roll);
-            yaw = normalize_angle(yaw);
-            angle_to_target = normalize_angle(angle_to_target);
-            angvel_loc.x *= p.angular_velocity_scale;
-            angvel_loc.y *= p.angular_velocity_scale;
-            angvel_loc.z *= p.angular_velocity_scale;
-        }
-        *reinterpret_cast<float4 *>(row + 0) = make_float4(pos.z, vel_loc.x, vel_loc.y, vel_loc.z);
-        *reinterpret_cast<float4 *>(row + 4) = make_float4(angvel_loc.x, angvel_loc.y, angvel_loc.z, yaw);
-        *reinterpret_cast<float4 *>(row + 8) = make_float4(roll, angle_to_target, up_proj, heading_proj);
-
-        // compute_*_reward, from this environment's own observation row
-        float act[D], dpos[D], dvel[D], tmp[D];
-        read_cols<D, L::C_ACT, NOBS>(row, act);
-        read_cols<D, L::C_POS, NOBS>(row, dpos);
-        read_cols<D, L::C_VEL, NOBS>(row, dvel);
-        const float heading_reward = (heading_proj > 0.8f) ? p.heading_weight : p.heading_weight * heading_proj / 0.8f;
-        const float up_reward = (up_proj > 0.93f) ? 0.0f + p.up_weight : 0.0f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) tmp[j] = act[j] * act[j];
-        const float actions_cost = row_sum<D>(tmp);
-        const float progress_reward = pot - prev_pot;
-        float total;
-        if constexpr (!HUM) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * dvel[j]);
-            const float electricity_cost = row_sum<D>(tmp);
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) cnt += (dpos[j] > 0.99f) ? 1 : 0;
-            total = progress_reward + 0.5f + up_reward + heading_reward - p.actions_cost_scale * actions_cost -
-                    p.energy_cost_scale * electricity_cost - (float)cnt * p.joints_at_limit_cost_scale;
-        } else {
-            float ratio[D];
-#pragma unroll
-            for (int j = 0; j < D; ++j) ratio[j] = p.motor_efforts[j] / p.max_motor_effort;
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                float ab = fabsf(dpos[j]);
-                float scaled = p.joints_at_limit_cost_scale * (ab - 0.98f) / 0.02f;
-                tmp[j] = ((ab > 0.98f) ? 1.0f : 0.0f) * scaled * ratio[j];
-            }
-            const float dof_at_limit_cost = row_sum<D>(tmp);
-#pragma unroll
-            for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * dvel[j]) * ratio[j];
-            const float electricity_cost = row_sum<D>(tmp);
-            total = progress_reward + 2.0f + up_reward + heading_reward - p.actions_cost_scale * actions_cost -
-                    p.energy_cost_scale * electricity_cost - dof_at_limit_cost;
-        }
-        if (pos.z < p.termination_height) {
-            total = p.death_cost;
-            rst = 1;
-        }
-        if ((float)prog >= p.max_episode_length_m1) rst = 1;
-
-        b.potentials[e] = pot;
-        b.prev_potentials[e] = prev_pot;
-        b.rew[e] = total;
-        b.reset[e] = rst;
-        b.progress[e] = prog;
-        float *uv = b.up_vec + e * 3;
-        uv[0] = up_vec.x; uv[1] = up_vec.y; uv[2] = up_vec.z;
-        float *hv = b.heading_vec + e * 3;
-        hv[0] = heading_vec.x; hv[1] = heading_vec.y; hv[2] = heading_vec.z;
-        if (b.true_objective) b.true_objective[e] = lin.x;
+    // compute_*_observations
+    const f3 to_target{p.targets[0] - pos.x, p.targets[1] - pos.y, 0.0f};
+    const float prev_pot = pot;
+    pot = -norm3(to_target) / p.dt;
+    const f3 target_dirs = normalize3(to_target);
+    const f4 isr{p.inv_start_rot[0], p.inv_start_rot[1], p.inv_start_rot[2], p.inv_start_rot[3]};
+    const f4 tq = quat_mul(rot, isr);
+    up_vec = quat_rotate<false>(tq, f3{p.basis_vec1[0], p.basis_vec1[1], p.basis_vec1[2]});
+    heading_vec = quat_rotate<false>(tq, f3{p.basis_vec0[0], p.basis_vec0[1], p.basis_vec0[2]});
+    const float up_proj = up_vec.z;
+    const float heading_proj = dot3(heading_vec, target_dirs);
+    const f3 vel_loc = quat_rotate<true>(tq, lin);
+    f3 angvel_loc = quat_rotate<true>(tq, ang);
+    float roll, yaw;
+    euler_roll_yaw(tq, roll, yaw);
+    float angle_to_target = atan2f(p.targets[2] - pos.z, p.targets[0] - pos.x) - yaw;
+    if constexpr (HUM) {
+        roll = normalize_angle(roll);
+        yaw = normalize_angle(yaw);
+        angle_to_target = normalize_angle(angle_to_target);
+        angvel_loc.x *= p.angular_velocity_scale;
+        angvel_loc.y *= p.angular_velocity_scale;
+        angvel_loc.z *= p.angular_velocity_scale;
     }
-    __syncthreads();
+    *reinterpret_cast<v4f *>(row + 0) = v4f{pos.z, vel_loc.x, vel_loc.y, vel_loc.z};
+    *reinterpret_cast<v4f *>(row + 4) = v4f{angvel_loc.x, angvel_loc.y, angvel_loc.z, yaw};
+    *reinterpret_cast<v4f *>(row + 8) = v4f{roll, angle_to_target, up_proj, heading_proj};
 
-    // ---- phase 3: finished rows out
-    copy_out<TILE, FULL, NOBS>(b.obs + base * NOBS, s_tile, nvalid, tid);
+    // compute_*_reward, from this environment's own observation row
+    float act[D], dpos[D], dvel[D], tmp[D];
+    read_cols<D, L::C_ACT, NOBS>(row, act);
+    read_cols<D, L::C_POS, NOBS>(row, dpos);
+    read_cols<D, L::C_VEL, NOBS>(row, dvel);
+    const float heading_reward = (heading_proj > 0.8f) ? p.heading_weight : p.heading_weight * heading_proj / 0.8f;
+    const float up_reward = (up_proj > 0.93f) ? 0.0f + p.up_weight : 0.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) tmp[j] = act[j] * act[j];
+    const float actions_cost = row_sum<D>(tmp);
+    const float progress_reward = pot - prev_pot;
+    float total;
+    if constexpr (!HUM) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * dvel[j]);
+        const float electricity_cost = row_sum<D>(tmp);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cnt += (dpos[j] > 0.99f) ? 1 : 0;
+        total = progress_reward + 0.5f + up_reward + heading_reward - p.actions_cost_scale * actions_cost -
+                p.energy_cost_scale * electricity_cost - (float)cnt * p.joints_at_limit_cost_scale;
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float ab = fabsf(dpos[j]);
+            const float scaled = p.joints_at_limit_cost_scale * (ab - 0.98f) / 0.02f;
+            tmp[j] = ((ab > 0.98f) ? 1.0f : 0.0f) * scaled * s_lim[2 * D + j];
+        }
+        const float dof_at_limit_cost = row_sum<D>(tmp);
+#pragma unroll
+        for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * dvel[j]) * s_lim[2 * D + j];
+        const float electricity_cost = row_sum<D>(tmp);
+        total = progress_reward + 2.0f + up_reward + heading_reward - p.actions_cost_scale * actions_cost -
+                p.energy_cost_scale * electricity_cost - dof_at_limit_cost;
+    }
+    if (pos.z < p.termination_height) {
+        total = p.death_cost;
+        rst = 1;
+    }
+    if ((float)prog >= p.max_episode_length_m1) rst = 1;
+
+    st_stream(b.potentials + e, pot);
+    st_stream(b.prev_potentials + e, prev_pot);
+    st_stream(b.rew + e, total);
+    st_stream(b.reset + e, rst);
+    st_stream(b.progress + e, prog);
+    if (b.true_objective) st_stream(b.true_objective + e, lin.x);
 }
 
-template <int D, int S, bool HUM, int TILE>
-__global__ __launch_bounds__(TILE) void loco_step_kernel(const igx_loco_params p, const igx_loco_buffers b, int64_t n)
+template <int D, int S, bool HUM>
+__global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p, const igx_loco_buffers b, int64_t n)
 {
     using L = LocoLayout<D, S, HUM>;
-    __shared__ __align__(16) float s_tile[TILE * L::NOBS];
-    __shared__ __align__(16) float s_root[TILE * 13];
-    __shared__ float s_lim[2 * D];
-    const int64_t base = (int64_t)blockIdx.x * TILE;
-    const int64_t left = n - base;
-    if (left >= TILE)
-        loco_tile<D, S, HUM, TILE, true>(p, b, n, base, TILE, s_tile, s_root, s_lim);
-    else
-        loco_tile<D, S, HUM, TILE, false>(p, b, n, base, (int)left, s_tile, s_root, s_lim);
+    constexpr int NOBS = L::NOBS;
+    static_assert(NOBS % 4 == 0, "observation rows must be a multiple of 16 bytes");
+    static_assert(NOBS >= 13, "the root rows are transposed through the observation tile");
+    __shared__ __align__(16) float s_tile[WAVE * NOBS];
+    // per-dof constants: [0,D) lower limit, [D,2D) upper limit, [2D,3D) motor effort ratio
+    __shared__ __align__(16) float s_lim[(3 * D + 4) & ~3];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
+    const bool full = nvalid == WAVE;
+    const bool live = lane < nvalid;
+    const int64_t e = base + lane;
+
+    if (lane < 2 * D) s_lim[lane] = (lane < D) ? p.dof_limits_lower[lane] : p.dof_limits_upper[lane - D];
+    if (HUM && lane < D) s_lim[2 * D + lane] = p.motor_efforts[lane] / p.max_motor_effort;
+
+    // ---- load: everything this tile reads, issued back to back
+    int64_t prog = 0, rst = 0, rnd = 0;
+    float pot = 0.0f;
+    v4f r_root[L::IT_ROOT], r_dof[L::IT_DOF], r_sens[L::IT_SENS], r_act[L::IT_ACT], r_force[HUM ? L::IT_ACT : 1];
+    if (live) {
+        prog = ld_stream(b.progress + e);
+        rst = ld_stream(b.reset + e);
+        pot = ld_stream(b.potentials + e);
+        if (b.randomize) rnd = ld_stream(b.randomize + e);
+    }
+    if (full) {
+        load_chunks<L::ROOT4>(b.root_states + base * 13, r_root, lane);
+        load_chunks<L::DOF4>(b.dof_state + base * (2 * D), r_dof, lane);
+        load_chunks<L::SENS4>(b.sensors + base * S, r_sens, lane);
+        load_chunks<L::ACT4>(b.actions + base * D, r_act, lane);
+        if constexpr (HUM) load_chunks<L::ACT4>(b.dof_force + base * D, r_force, lane);
+    }
+
+    // ---- root: transpose the 13-float rows through the (still empty) tile
+    if (full) {
+#pragma unroll
+        for (int it = 0; it < L::IT_ROOT; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= L::ROOT4 || k < L::ROOT4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_root[it];
+        }
+    } else {
+        for (int i = lane; i < nvalid * 13; i += WAVE) s_tile[i] = b.root_states[base * 13 + i];
+    }
+    wave_sync();
+    float rr[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) rr[i] = s_tile[lane * 13 + i];  // lanes >= nvalid read stale LDS, never used
+    wave_sync();
+
+    // ---- stage: pass-through columns into the observation rows
+    if (full) {
+        stage_dof_state<D, NOBS, L::C_POS, L::C_VEL>(r_dof, s_tile, s_lim, p.dof_vel_scale, lane);
+        stage_rows<S, L::C_SENS, NOBS, true>(r_sens, s_tile, p.contact_force_scale, lane);
+        stage_rows<D, L::C_ACT, NOBS, false>(r_act, s_tile, 1.0f, lane);
+        if constexpr (HUM) stage_rows<D, L::C_FORCE, NOBS, true>(r_force, s_tile, p.contact_force_scale, lane);
+    } else {  // the one partial tile at the end of the batch: plain scalar staging
+        for (int i = lane; i < nvalid * D; i += WAVE) {
+            const int env = i / D, j = i - env * D;
+            const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * D + i];
+            s_tile[env * NOBS + L::C_POS + j] = unscale(pv.x, s_lim[j], s_lim[D + j]);
+            s_tile[env * NOBS + L::C_VEL + j] = pv.y * p.dof_vel_scale;
+            s_tile[env * NOBS + L::C_ACT + j] = b.actions[base * D + i];
+            if constexpr (HUM) s_tile[env * NOBS + L::C_FORCE + j] = b.dof_force[base * D + i] * p.contact_force_scale;
+        }
+        for (int i = lane; i < nvalid * S; i += WAVE) {
+            const int env = i / S, c = i - env * S;
+            s_tile[env * NOBS + L::C_SENS + c] = b.sensors[base * S + i] * p.contact_force_scale;
+        }
+    }
+    wave_sync();
+
+    // ---- reset: re-draw the joints of flagged environments (rare)
+    const uint64_t reset_mask = __ballot(live && rst != 0);
+    if (reset_mask) {
+        reset_joints<D, S, HUM>(p, b, base, lane, reset_mask, s_tile, s_lim);
+        wave_sync();
+    }
+
+    // ---- per-env math
+    f3 up_vec{0, 0, 0}, heading_vec{0, 0, 0};
+    if (live) per_env<D, S, HUM>(p, b, e, rr, prog, rst, rnd, pot, s_tile + lane * NOBS, s_lim, up_vec, heading_vec);
+    wave_sync();
+
+    // ---- drain: finished rows out as whole lines
+    if (full) {
+        constexpr int N4 = WAVE * NOBS / 4;
+        v4f *o4 = reinterpret_cast<v4f *>(b.obs + base * NOBS);
+#pragma unroll
+        for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= N4 || k < N4) st_stream(o4 + k, *reinterpret_cast<const v4f *>(s_tile + 4 * k));
+        }
+    } else {
+        for (int i = lane; i < nvalid * NOBS; i += WAVE) b.obs[base * NOBS + i] = s_tile[i];
+    }
+    wave_sync();
+    // up / heading vectors: transpose through the tile's first 384 floats
+    s_tile[lane * 3 + 0] = up_vec.x; s_tile[lane * 3 + 1] = up_vec.y; s_tile[lane * 3 + 2] = up_vec.z;
+    s_tile[192 + lane * 3 + 0] = heading_vec.x;
+    s_tile[192 + lane * 3 + 1] = heading_vec.y;
+    s_tile[192 + lane * 3 + 2] = heading_vec.z;
+    wave_sync();
+    if (full) {
+        if (lane < 48) {  // 192 floats = 48 chunks per array
+            st_stream(reinterpret_cast<v4f *>(b.up_vec + base * 3) + lane,
+                      *reinterpret_cast<const v4f *>(s_tile + 4 * lane));
+            st_stream(reinterpret_cast<v4f *>(b.heading_vec + base * 3) + lane,
+                      *reinterpret_cast<const v4f *>(s_tile + 192 + 4 * lane));
+        }
+    } else {
+        for (int i = lane; i < nvalid * 3; i += WAVE) {
+            b.up_vec[base * 3 + i] = s_tile[i];
+            b.heading_vec[base * 3 + i] = s_tile[192 + i];
+        }
+    }
 }
 
 static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int D, int S, bool hum,
                       const char *who)
 {
     if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
-    if (n < 0 || n > ((int64_t)1 << 40)) return fail(IGX_E_SIZE, "%s: n_envs %lld out of range", who, (long long)n);
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "%s: n_envs %lld out of range", who, (long long)n);
     if (p->num_dof != D || p->num_sensor_floats != S)
         return fail(IGX_E_PARAM, "%s: expects num_dof=%d num_sensor_floats=%d, got %d/%d", who, D, S, p->num_dof,
                     p->num_sensor_floats);
@@ -387,7 +480,7 @@ static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64
         {b->sensors, "sensors", true}, {b->actions, "actions", true},
         {b->initial_root_states, "initial_root_states", false}, {b->initial_dof_pos, "initial_dof_pos", false},
         {b->obs, "obs", true}, {b->potentials, "potentials", false}, {b->prev_potentials, "prev_potentials", false},
-        {b->up_vec, "up_vec", false}, {b->heading_vec, "heading_vec", false}, {b->rew, "rew", false},
+        {b->up_vec, "up_vec", true}, {b->heading_vec, "heading_vec", true}, {b->rew, "rew", false},
         {b->reset, "reset", false}, {b->progress, "progress", false}};
     for (const auto &r : req) {
         if (!r.ptr) return fail(IGX_E_NULL, "%s: %s is NULL", who, r.name);
@@ -401,32 +494,25 @@ static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64
     return IGX_OK;
 }
 
-template <int D, int S, bool HUM, int TILE>
+template <int D, int S, bool HUM>
 static int launch_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, igx_stream_t stream,
                        const char *who)
 {
     if (n == 0) return IGX_OK;
-    const int64_t tiles = (n + TILE - 1) / TILE;
-    if (tiles > 0x7fffffffLL) return fail(IGX_E_SIZE, "%s: too many tiles", who);
-    hipLaunchKernelGGL((loco_step_kernel<D, S, HUM, TILE>), dim3((unsigned)tiles), dim3(TILE), 0,
+    const int64_t tiles = (n + WAVE - 1) / WAVE;
+    if (tiles > 0x7fffffffLL) return fail(IGX_E_SIZE, "%s: n_envs too large for one launch", who);
+    hipLaunchKernelGGL((loco_step_kernel<D, S, HUM>), dim3((unsigned)tiles), dim3(WAVE), 0,
                        static_cast<hipStream_t>(stream), *p, *b, n);
     return launch_status(who);
 }
 
 }  // namespace igx
 
-#ifndef IGX_ANT_TILE
-#define IGX_ANT_TILE 256
-#endif
-#ifndef IGX_HUMANOID_TILE
-#define IGX_HUMANOID_TILE 128
-#endif
-
 extern "C" int igx_ant_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n_envs, igx_stream_t stream)
 {
     int rc = igx::check_loco(p, b, n_envs, 8, 24, false, "igx_ant_step");
     if (rc != IGX_OK) return rc;
-    return igx::launch_loco<8, 24, false, IGX_ANT_TILE>(p, b, n_envs, stream, "igx_ant_step");
+    return igx::launch_loco<8, 24, false>(p, b, n_envs, stream, "igx_ant_step");
 }
 
 extern "C" int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n_envs,
@@ -434,5 +520,5 @@ extern "C" int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffer
 {
     int rc = igx::check_loco(p, b, n_envs, 21, 12, true, "igx_humanoid_step");
     if (rc != IGX_OK) return rc;
-    return igx::launch_loco<21, 12, true, IGX_HUMANOID_TILE>(p, b, n_envs, stream, "igx_humanoid_step");
+    return igx::launch_loco<21, 12, true>(p, b, n_envs, stream, "igx_humanoid_step");
 }

@@ -25,6 +25,23 @@
 
 #define TWO_PI_F 6.2831855f /* float32(2*np.pi) */
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* Environments are independent, so the per-env loops below are split over
+ * host threads (used for the CPU-baseline timing); results do not depend on
+ * the thread count. */
+int orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* ---------------------------------------------------------------- RNG --- */
 /* Philox4x32-10 (Salmon et al. 2011), the counter-based generator the
  * library uses when no pre-drawn uniforms are supplied.  Not part of the
@@ -214,6 +231,7 @@ static float row_sum(const float *x, int D)
 int orc_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *b, int64_t n)
 {
     const float half_pi = 1.57079637f; /* float32(np.pi / 2) */
+#pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < n; ++e) {
         float *ds = b->dof_state + e * 4;
         int64_t prog = b->progress[e] + 1;
@@ -258,6 +276,7 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
     float ratio[IGX_MAX_DOF];
     for (int j = 0; j < D; ++j) ratio[j] = humanoid ? p->motor_efforts[j] / p->max_motor_effort : 0.0f;
 
+#pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < n; ++e) {
         const float *root = b->root_states + e * 13;
         float *ds = b->dof_state + e * D * 2;

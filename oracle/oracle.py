@@ -48,6 +48,11 @@ def _call(fn, params, bufcls, bufs, n):
         raise RuntimeError("oracle call failed: %d" % rc)
 
 
+def set_num_threads(n):
+    """Set (n > 0) and return the number of host threads the checker uses."""
+    return int(lib().orc_set_num_threads(int(n)))
+
+
 def philox_uniform(seed, offset, env, j):
     return float(lib().orc_philox_uniform(seed, offset, env, j))
 

@@ -1,0 +1,149 @@
+// Access-pattern skeleton of the Ant step (same arrays, same bytes per env,
+// no math): what launch shape streams this multi-array pattern fastest?
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <string>
+using v4f = float __attribute__((ext_vector_type(4)));
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+struct Bufs { const float *root, *dof, *sens, *act; float *pot, *prev, *up, *head, *rew, *obs; int64_t *reset, *prog, *rnd; };
+
+// TPB threads per block, each wave handles its own 64-env tile(s); PERSIST: grid-stride over tiles with prefetch
+template <int TPB, bool PERSIST, bool NT>
+__global__ __launch_bounds__(TPB) void skel(Bufs b, int64_t ntiles)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    constexpr int WPB = TPB / 64;
+    int64_t tile = (int64_t)blockIdx.x * WPB + wib;
+    const int64_t tstride = (int64_t)gridDim.x * WPB;
+    auto LD = [&](const v4f *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+    auto ST = [&](v4f *p, v4f v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+    v4f r[16]; float pot; int64_t rs, pg, rn;
+    auto load = [&](int64_t t) {
+        const int64_t base = t * 64;
+        const v4f *g;
+        g = (const v4f *)(b.root + base * 13);
+        r[0] = LD(g + lane); r[1] = LD(g + 64 + lane); r[2] = LD(g + 128 + lane); r[3] = LD(g + 192 + (lane & 15));
+        g = (const v4f *)(b.dof + base * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[4 + i] = LD(g + 64 * i + lane);
+        g = (const v4f *)(b.sens + base * 24);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[8 + i] = LD(g + 64 * i + lane);
+        g = (const v4f *)(b.act + base * 8);
+        r[14] = LD(g + lane); r[15] = LD(g + 64 + lane);
+        pot = b.pot[base + lane]; rs = b.reset[base + lane]; pg = b.prog[base + lane]; rn = b.rnd[base + lane];
+    };
+    if (tile < ntiles) load(tile);
+    while (tile < ntiles) {
+        const int64_t base = tile * 64;
+        v4f o[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) o[i] = r[i] + r[15];
+        float p0 = pot; int64_t a = rs, c = pg, d = rn;
+        v4f u = r[3], h = r[7];
+        if (PERSIST) { int64_t nx = tile + tstride; if (nx < ntiles) load(nx); }
+        v4f *og = (v4f *)(b.obs + base * 60);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) ST(og + 64 * i + lane, o[i]);
+        b.pot[base + lane] = p0 + 1.0f; b.prev[base + lane] = p0; b.rew[base + lane] = p0 * 2.0f;
+        b.reset[base + lane] = a ^ 1; b.prog[base + lane] = c + 1; b.rnd[base + lane] = d + 1;
+        if (lane < 48) { ST((v4f *)(b.up + base * 3) + lane, u); ST((v4f *)(b.head + base * 3) + lane, h); }
+        if (!PERSIST) break;
+        tile += tstride;
+    }
+}
+
+// one-shot, obs rows written as three partial-row segments per env
+// (cols 0..27 | sensors 28..51 | actions 52..59) instead of linear full rows
+template <int TPB, bool NT>
+__global__ __launch_bounds__(TPB) void skel_split(Bufs b, int64_t ntiles)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    auto LD = [&](const v4f *p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+    auto ST = [&](v4f *p, v4f v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+    v4f r[16];
+    const int64_t base = tile * 64;
+    const v4f *g;
+    g = (const v4f *)(b.root + base * 13);
+    r[0] = LD(g + lane); r[1] = LD(g + 64 + lane); r[2] = LD(g + 128 + lane); r[3] = LD(g + 192 + (lane & 15));
+    g = (const v4f *)(b.dof + base * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[4 + i] = LD(g + 64 * i + lane);
+    g = (const v4f *)(b.sens + base * 24);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[8 + i] = LD(g + 64 * i + lane);
+    g = (const v4f *)(b.act + base * 8);
+    r[14] = LD(g + lane); r[15] = LD(g + 64 + lane);
+    float pot = b.pot[base + lane]; int64_t rs = b.reset[base + lane], pg = b.prog[base + lane], rn = b.rnd[base + lane];
+    v4f *og = (v4f *)(b.obs + base * 60);
+    // sensors: chunk k = lane + 64 i -> env k/6, part k%6, at float4 index env*15 + 7 + part
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { int k = lane + 64 * i; int env = k / 6, part = k - env * 6; ST(og + env * 15 + 7 + part, r[8 + i] * 0.1f); }
+    // cols 0..27: 7 float4 per env = 448 chunks
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { int k = lane + 64 * i; int env = k / 7, part = k - env * 7; ST(og + env * 15 + part, r[i] + r[7]); }
+    // actions: 2 float4 per env
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { int k = lane + 64 * i; int env = k >> 1, part = k & 1; ST(og + env * 15 + 13 + part, r[14 + i]); }
+    b.pot[base + lane] = pot + 1.0f; b.prev[base + lane] = pot; b.rew[base + lane] = pot * 2.0f;
+    b.reset[base + lane] = rs ^ 1; b.prog[base + lane] = pg + 1; b.rnd[base + lane] = rn + 1;
+    if (lane < 48) { ST((v4f *)(b.up + base * 3) + lane, r[3]); ST((v4f *)(b.head + base * 3) + lane, r[7]); }
+}
+
+template <class F>
+static double time_ms(F f, int iters)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) f(i);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) f(i);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+int main()
+{
+    const int64_t N = 1 << 20, ntiles = N / 64;
+    const int NS = 3;
+    Bufs s[NS];
+    for (int i = 0; i < NS; ++i) {
+        auto A = [&](size_t bytes) { void *p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0, bytes)); return p; };
+        s[i].root = (float *)A(N * 13 * 4); s[i].dof = (float *)A(N * 16 * 4); s[i].sens = (float *)A(N * 24 * 4); s[i].act = (float *)A(N * 8 * 4);
+        s[i].pot = (float *)A(N * 4); s[i].prev = (float *)A(N * 4); s[i].up = (float *)A(N * 12); s[i].head = (float *)A(N * 12); s[i].rew = (float *)A(N * 4);
+        s[i].obs = (float *)A(N * 240); s[i].reset = (int64_t *)A(N * 8); s[i].prog = (int64_t *)A(N * 8); s[i].rnd = (int64_t *)A(N * 8);
+    }
+    const double bytes = 556.0 * N;
+    printf("{");
+    bool first = true;
+    auto emit = [&](const std::string &name, double ms) { printf("%s\"%s\": [%.1f, %.0f]", first ? "" : ", ", name.c_str(), ms * 1e3, bytes / ms / 1e6); first = false; fflush(stdout); };
+#define RUN(TPB, PERSIST, NT, GRID, NAME) emit(NAME, time_ms([&](int i) { hipLaunchKernelGGL((skel<TPB, PERSIST, NT>), dim3(GRID), dim3(TPB), 0, 0, s[i % NS], ntiles); }, 30))
+    RUN(64, false, false, (unsigned)ntiles, "oneshot_w64");
+    RUN(64, false, true, (unsigned)ntiles, "oneshot_w64_nt");
+    RUN(256, false, false, (unsigned)(ntiles / 4), "oneshot_b256");
+    RUN(256, false, true, (unsigned)(ntiles / 4), "oneshot_b256_nt");
+    RUN(512, false, false, (unsigned)(ntiles / 8), "oneshot_b512");
+    RUN(1024, false, false, (unsigned)(ntiles / 16), "oneshot_b1024");
+#define RUNS(TPB, NT, GRID, NAME) emit(NAME, time_ms([&](int i) { hipLaunchKernelGGL((skel_split<TPB, NT>), dim3(GRID), dim3(TPB), 0, 0, s[i % NS], ntiles); }, 30))
+    RUNS(64, true, (unsigned)ntiles, "split_w64_nt");
+    RUNS(256, true, (unsigned)(ntiles / 4), "split_b256_nt");
+    RUNS(256, false, (unsigned)(ntiles / 4), "split_b256");
+    RUN(64, true, false, 2048, "persist_w64_g2048");
+    RUN(64, true, false, 4096, "persist_w64_g4096");
+    RUN(64, true, false, 8192, "persist_w64_g8192");
+    RUN(256, true, false, 512, "persist_b256_g512");
+    RUN(256, true, false, 1024, "persist_b256_g1024");
+    RUN(256, true, false, 2048, "persist_b256_g2048");
+    RUN(256, true, true, 2048, "persist_b256_g2048_nt");
+    printf("}\n");
+    return 0;
+}

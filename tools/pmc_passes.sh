@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collect PMC counters for the benchmark kernel, one rocprofv3 run per pass
+# (counter blocks have few slots; rocprofv3 does not split passes itself).
+# usage: tools/pmc_passes.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+PASSES=(
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+ "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
+ "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_EA0_RDREQ_128B_sum"
+ "GRBM_GUI_ACTIVE TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
+)
+i=0
+for P in "${PASSES[@]}"; do
+  i=$((i+1))
+  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "$OUT/pass$i.log" 2>&1
+  rc=$?
+  echo "pass $i ($P) rc=$rc"
+  if [ $rc -ne 0 ]; then tail -5 "$OUT/pass$i.log"; exit 1; fi
+done
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" | tee "$OUT/summary.json"
