@@ -132,6 +132,41 @@ int igx_ant_step(const igx_loco_params *p, const igx_loco_buffers *b,
 int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b,
                       int64_t n_envs, igx_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * torch_jit_utils math, one batched call per reference function
+ * (utils/torch_jit_utils.py).  Quaternions are [n,4] xyzw, vectors [n,3],
+ * all fp32 contiguous; `out` may alias an input of the same shape.
+ * ---------------------------------------------------------------------- */
+/* :41-62 quat_mul(a, b) */
+int igx_quat_mul(const float *a, const float *b, float *out, int64_t n, igx_stream_t stream);
+/* :106-110 quat_conjugate(a) */
+int igx_quat_conjugate(const float *a, float *out, int64_t n, igx_stream_t stream);
+/* :80-90 quat_rotate(q, v) (also :411-421 my_quat_rotate) */
+int igx_quat_rotate(const float *q, const float *v, float *out, int64_t n, igx_stream_t stream);
+/* :93-103 quat_rotate_inverse(q, v) */
+int igx_quat_rotate_inverse(const float *q, const float *v, float *out, int64_t n, igx_stream_t stream);
+/* :595-628 slerp(q0, q1, t); t is [n] (one blend per quaternion, may be outside [0,1]) */
+int igx_slerp(const float *q0, const float *q1, const float *t, float *out, int64_t n, igx_stream_t stream);
+/* :234-236 scale, :239-241 unscale, :228-230 tensor_clamp: x is [n,d]; lower / upper are [d] */
+int igx_scale(const float *x, const float *lower, const float *upper, float *out, int64_t n, int32_t d,
+              igx_stream_t stream);
+int igx_unscale(const float *x, const float *lower, const float *upper, float *out, int64_t n, int32_t d,
+                igx_stream_t stream);
+int igx_tensor_clamp(const float *x, const float *lower, const float *upper, float *out, int64_t n, int32_t d,
+                     igx_stream_t stream);
+/* :118-123 quat_from_angle_axis(angle [n], axis [n,3]) */
+int igx_quat_from_angle_axis(const float *angle, const float *axis, float *out, int64_t n, igx_stream_t stream);
+/* :126-128 normalize_angle(x [n]) */
+int igx_normalize_angle(const float *x, float *out, int64_t n, igx_stream_t stream);
+/* :454-461 quat_to_exp_map(q) -> [n,3] */
+int igx_quat_to_exp_map(const float *q, float *out, int64_t n, igx_stream_t stream);
+/* :589-593 exp_map_to_quat(e [n,3]) -> [n,4] */
+int igx_exp_map_to_quat(const float *e, float *out, int64_t n, igx_stream_t stream);
+/* :548-561 quat_to_tan_norm(q) -> [n,6] */
+int igx_quat_to_tan_norm(const float *q, float *out, int64_t n, igx_stream_t stream);
+/* :656-667 calc_heading_quat_inv(q) -> [n,4] */
+int igx_calc_heading_quat_inv(const float *q, float *out, int64_t n, igx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,15 @@ SYMBOLS = {
     "igx_ant_step": _STEP_SIG,
     "igx_humanoid_step": _STEP_SIG,
 }
+# batched torch_jit_utils math: (inputs..., out, n[, d], stream)
+_I64 = C.c_int64
+for _name, _nin in (("igx_quat_mul", 2), ("igx_quat_conjugate", 1), ("igx_quat_rotate", 2),
+                    ("igx_quat_rotate_inverse", 2), ("igx_slerp", 3), ("igx_quat_from_angle_axis", 2),
+                    ("igx_normalize_angle", 1), ("igx_quat_to_exp_map", 1), ("igx_exp_map_to_quat", 1),
+                    ("igx_quat_to_tan_norm", 1), ("igx_calc_heading_quat_inv", 1)):
+    SYMBOLS[_name] = (C.c_int, [_P] * (_nin + 1) + [_I64, _P])
+for _name in ("igx_scale", "igx_unscale", "igx_tensor_clamp"):
+    SYMBOLS[_name] = (C.c_int, [_P, _P, _P, _P, _I64, C.c_int32, _P])
 
 
 class IgxError(RuntimeError):
@@ -114,4 +123,24 @@ def call_step(symbol, params, bufcls, tensors, n):
         raise ValueError("no device buffers given")
     with torch.cuda.device(dev):
         rc = getattr(lib(), symbol)(C.byref(params), C.byref(b), C.c_int64(n), current_stream(dev))
+    check(rc)
+
+
+def call_rowwise(symbol, inputs, out, n):
+    """inputs: contiguous fp32 device tensors; out: preallocated device tensor."""
+    dev = out.device
+    ptrs = [tensor_ptr(t, torch.float32) for t in inputs] + [tensor_ptr(out, torch.float32)]
+    for t in inputs:
+        if t.device != dev:
+            raise ValueError("all tensors must live on %s" % dev)
+    with torch.cuda.device(dev):
+        rc = getattr(lib(), symbol)(*ptrs, C.c_int64(n), current_stream(dev))
+    check(rc)
+
+
+def call_affine(symbol, x, lower, upper, out, n, d):
+    dev = out.device
+    ptrs = [tensor_ptr(t, torch.float32) for t in (x, lower, upper, out)]
+    with torch.cuda.device(dev):
+        rc = getattr(lib(), symbol)(*ptrs, C.c_int64(n), C.c_int32(d), current_stream(dev))
     check(rc)

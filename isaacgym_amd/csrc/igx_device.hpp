@@ -120,6 +120,87 @@ __device__ __forceinline__ float scale(float x, float lo, float hi) { return 0.5
 // :228-230 tensor_clamp
 __device__ __forceinline__ float tensor_clamp(float t, float lo, float hi) { return fmaxf(fminf(t, hi), lo); }
 
+// :65-67 normalize applied to a quaternion (quat_unit, :113-115)
+__device__ __forceinline__ f4 quat_unit(f4 q)
+{
+    float n = norm4(q);
+    n = (n < 1e-9f) ? 1e-9f : n;
+    return f4{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+
+// :118-123 quat_from_angle_axis: normalises the axis and the result
+__device__ __forceinline__ f4 quat_from_angle_axis(float angle, f3 axis)
+{
+    const float theta = angle / 2.0f;
+    const f3 a = normalize3(axis);
+    const float s = sinf(theta);
+    return quat_unit(f4{a.x * s, a.y * s, a.z * s, cosf(theta)});
+}
+
+// :570-587 exp_map_to_angle_axis + :589-593 exp_map_to_quat.  The reference
+// divides by a possibly zero angle and masks the result afterwards; the select
+// below reproduces the masked value without ever consuming the inf / nan.
+__device__ __forceinline__ f4 exp_map_to_quat(f3 e)
+{
+    const float n = norm3(e);
+    f3 axis{e.x / n, e.y / n, e.z / n};
+    float angle = normalize_angle(n);
+    const bool mask = angle > 1e-5f;
+    angle = mask ? angle : 0.0f;
+    axis = mask ? axis : f3{0.0f, 0.0f, 1.0f};
+    return quat_from_angle_axis(angle, axis);
+}
+
+// :423-444 quat_to_angle_axis
+__device__ __forceinline__ void quat_to_angle_axis(f4 q, float &angle, f3 &axis)
+{
+    const float sin_theta = sqrtf(1.0f - q.w * q.w);
+    angle = normalize_angle(2.0f * acosf(q.w));
+    axis = f3{q.x / sin_theta, q.y / sin_theta, q.z / sin_theta};
+    const bool mask = sin_theta > 1e-5f;
+    angle = mask ? angle : 0.0f;
+    axis = mask ? axis : f3{0.0f, 0.0f, 1.0f};
+}
+
+// :454-461 quat_to_exp_map
+__device__ __forceinline__ f3 quat_to_exp_map(f4 q)
+{
+    float angle;
+    f3 axis;
+    quat_to_angle_axis(q, angle, axis);
+    return f3{angle * axis.x, angle * axis.y, angle * axis.z};
+}
+
+// :595-628 slerp; t may lie outside [0,1] (the motion library extrapolates)
+__device__ __forceinline__ f4 slerp(f4 q0, f4 q1, float t)
+{
+    float c = q0.w * q1.w + q0.x * q1.x + q0.y * q1.y + q0.z * q1.z;
+    if (c < 0.0f) q1 = f4{-q1.x, -q1.y, -q1.z, -q1.w};
+    c = fabsf(c);
+    const float half_theta = acosf(c);
+    const float s = sqrtf(1.0f - c * c);
+    const float ra = sinf((1.0f - t) * half_theta) / s;
+    const float rb = sinf(t * half_theta) / s;
+    f4 o{ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w};
+    if (fabsf(s) < 0.001f) o = f4{0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z,
+                                  0.5f * q0.w + 0.5f * q1.w};
+    if (fabsf(c) >= 1.0f) o = q0;
+    return o;
+}
+
+// :630-641 calc_heading
+__device__ __forceinline__ float calc_heading(f4 q)
+{
+    const f3 d = quat_rotate<false>(q, f3{1.0f, 0.0f, 0.0f});
+    return atan2f(d.y, d.x);
+}
+
+// :656-667 calc_heading_quat_inv
+__device__ __forceinline__ f4 calc_heading_quat_inv(f4 q)
+{
+    return quat_from_angle_axis(-calc_heading(q), f3{0.0f, 0.0f, 1.0f});
+}
+
 // Philox4x32-10 counter-based generator (Salmon et al., SC'11).  Used for the
 // reset draws when the caller supplies no pre-drawn uniforms.  Counter layout:
 // (env lo, env hi, offset lo, offset hi[23:0] << 8 | block), key = seed.

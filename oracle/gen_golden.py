@@ -312,7 +312,79 @@ def gen_humanoid(seed=2, N=211, T=4):
     _gen_loco("humanoid", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, seed, N, T)
 
 
-GENERATORS = {"cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid}
+# --------------------------------------------------------------------------
+def gen_math(seed=3, n=1536):
+    """torch_jit_utils functions on random inputs plus the edge cases of each."""
+    _install_gym_stubs()
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    g = torch.Generator().manual_seed(seed)
+
+    def unit(q):
+        return q / q.norm(dim=-1, keepdim=True)
+
+    qa = unit(torch.randn(n, 4, generator=g))
+    qb = unit(torch.randn(n, 4, generator=g))
+    qa[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    qb[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    v = torch.randn(n, 3, generator=g)
+    v[1] = 0.0
+    out = {"qa": qa, "qb": qb, "v": v}
+    out["quat_mul"] = tj.quat_mul(qa, qb)
+    out["quat_conjugate"] = tj.quat_conjugate(qa)
+    out["quat_rotate"] = tj.quat_rotate(qa, v)
+    out["quat_rotate_inverse"] = tj.quat_rotate_inverse(qa, v)
+
+    # slerp: generic, antipodal (dot < 0), identical (|cos| >= 1), nearly
+    # parallel (sin < 0.001), blend outside [0, 1]
+    s0 = qa.clone()
+    s1 = qb.clone()
+    s1[10:20] = -s0[10:20]
+    s1[20:30] = s0[20:30]
+    s1[30:60] = unit(s0[30:60] + 1e-4 * torch.randn(30, 4, generator=g))
+    t = torch.rand(n, 1, generator=g)
+    t[60:90] = torch.rand(30, 1, generator=g) * 3 - 1.5
+    t[0] = 0.0
+    t[1] = 1.0
+    out.update(slerp_q0=s0, slerp_q1=s1, slerp_t=t, slerp=tj.slerp(s0, s1, t))
+
+    angle = (torch.rand(n, generator=g) * 2 - 1) * 4.0
+    axis = torch.randn(n, 3, generator=g)
+    angle[0] = 0.0
+    axis[1] = 0.0  # zero-norm axis: clamp(min=1e-9) path
+    out.update(angle=angle, axis=axis, quat_from_angle_axis=tj.quat_from_angle_axis(angle, axis))
+
+    x = (torch.rand(n, generator=g) * 2 - 1) * 10.0
+    x[:5] = torch.tensor([0.0, math.pi, -math.pi, 2 * math.pi, -0.0])
+    out.update(na_x=x, normalize_angle=tj.normalize_angle(x))
+
+    qe = qa.clone()
+    qe[2] = torch.tensor([0.0, 0.0, 0.0, 1.0])   # sin_theta == 0 -> default axis
+    qe[3] = torch.tensor([0.0, 0.0, 0.0, -1.0])
+    qe[4] = unit(torch.tensor([1e-6, 0.0, 0.0, 1.0]))
+    out.update(qe=qe, quat_to_exp_map=tj.quat_to_exp_map(qe))
+
+    e = torch.randn(n, 3, generator=g) * 1.5
+    e[0] = 0.0                                   # 0 / 0 lanes, masked by where
+    e[1] = torch.tensor([1e-7, 0.0, 0.0])
+    e[2] = torch.tensor([4.0, 0.0, 0.0])         # angle > pi wraps
+    out.update(e=e, exp_map_to_quat=tj.exp_map_to_quat(e))
+
+    out["quat_to_tan_norm"] = tj.quat_to_tan_norm(qa)
+    out["calc_heading_quat_inv"] = tj.calc_heading_quat_inv(qa)
+
+    d = 16
+    lo = -torch.rand(d, generator=g) - 0.2
+    hi = torch.rand(d, generator=g) + 0.3
+    xs = torch.randn(n, d, generator=g)
+    out.update(aff_x=xs, aff_lo=lo, aff_hi=hi, scale=tj.scale(xs, lo, hi), unscale=tj.unscale(xs, lo, hi),
+               tensor_clamp=tj.tensor_clamp(xs, lo, hi))
+    out = {k: v.numpy() for k, v in out.items()}
+    out["meta"] = _meta(task="torch_jit_utils", n=n, seed=seed)
+    np.savez_compressed(os.path.join(OUT, "math.npz"), **out)
+    print("math.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+GENERATORS = {"cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

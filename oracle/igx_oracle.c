@@ -414,3 +414,163 @@ int orc_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b, int64
 {
     return loco_step(p, b, n, 1);
 }
+
+/* ------------------------------------------- torch_jit_utils, batched --- */
+/* utils/torch_jit_utils.py:113-115 quat_unit = normalize of a 4-vector */
+static void quat_unit(const float q[4], float o[4])
+{
+    float n = norm4(q);
+    if (n < 1e-9f) n = 1e-9f;
+    for (int i = 0; i < 4; ++i) o[i] = q[i] / n;
+}
+
+/* :118-123 */
+static void quat_from_angle_axis(float angle, const float axis[3], float o[4])
+{
+    float theta = angle / 2.0f;
+    float a[3];
+    normalize3(axis, a);
+    float s = sinf(theta);
+    float q[4] = { a[0] * s, a[1] * s, a[2] * s, cosf(theta) };
+    quat_unit(q, o);
+}
+
+/* :570-593 exp_map_to_angle_axis + exp_map_to_quat */
+static void exp_map_to_quat(const float e[3], float o[4])
+{
+    float n = norm3(e);
+    float axis[3] = { e[0] / n, e[1] / n, e[2] / n };
+    float angle = normalize_angle(n);
+    if (!(angle > 1e-5f)) {
+        angle = 0.0f;
+        axis[0] = 0.0f; axis[1] = 0.0f; axis[2] = 1.0f;
+    }
+    quat_from_angle_axis(angle, axis, o);
+}
+
+/* :423-444 */
+static void quat_to_angle_axis(const float q[4], float *angle, float axis[3])
+{
+    float sin_theta = sqrtf(1.0f - q[3] * q[3]);
+    float a = normalize_angle(2.0f * acosf(q[3]));
+    if (sin_theta > 1e-5f) {
+        *angle = a;
+        axis[0] = q[0] / sin_theta; axis[1] = q[1] / sin_theta; axis[2] = q[2] / sin_theta;
+    } else {
+        *angle = 0.0f;
+        axis[0] = 0.0f; axis[1] = 0.0f; axis[2] = 1.0f;
+    }
+}
+
+/* :454-461 */
+static void quat_to_exp_map(const float q[4], float o[3])
+{
+    float angle, axis[3];
+    quat_to_angle_axis(q, &angle, axis);
+    for (int i = 0; i < 3; ++i) o[i] = angle * axis[i];
+}
+
+/* :595-628 */
+static void slerp(const float q0[4], const float q1in[4], float t, float o[4])
+{
+    float q1[4] = { q1in[0], q1in[1], q1in[2], q1in[3] };
+    float c = q0[3] * q1[3] + q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2];
+    if (c < 0.0f) for (int i = 0; i < 4; ++i) q1[i] = -q1[i];
+    c = fabsf(c);
+    float half_theta = acosf(c);
+    float s = sqrtf(1.0f - c * c);
+    float ra = sinf((1.0f - t) * half_theta) / s;
+    float rb = sinf(t * half_theta) / s;
+    for (int i = 0; i < 4; ++i) o[i] = ra * q0[i] + rb * q1[i];
+    if (fabsf(s) < 0.001f) for (int i = 0; i < 4; ++i) o[i] = 0.5f * q0[i] + 0.5f * q1[i];
+    if (fabsf(c) >= 1.0f) for (int i = 0; i < 4; ++i) o[i] = q0[i];
+}
+
+/* :630-641 / :656-667 */
+static void calc_heading_quat_inv(const float q[4], float o[4])
+{
+    const float ref[3] = { 1.0f, 0.0f, 0.0f }, zax[3] = { 0.0f, 0.0f, 1.0f };
+    float d[3];
+    quat_rotate_s(q, ref, d, 0);
+    float heading = atan2f(d[1], d[0]);
+    quat_from_angle_axis(-heading, zax, o);
+}
+
+/* :548-561 */
+static void quat_to_tan_norm(const float q[4], float o[6])
+{
+    const float rt[3] = { 1.0f, 0.0f, 0.0f }, rn[3] = { 0.0f, 0.0f, 1.0f };
+    quat_rotate_s(q, rt, o, 0);
+    quat_rotate_s(q, rn, o + 3, 0);
+}
+
+int orc_quat_mul(const float *a, const float *b, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[4]; quat_mul(a + 4 * i, b + 4 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}
+int orc_quat_conjugate(const float *a, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[4]; quat_conjugate(a + 4 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}
+int orc_quat_rotate(const float *q, const float *v, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[3]; quat_rotate_s(q + 4 * i, v + 3 * i, t, 0); memcpy(o + 3 * i, t, 12); }
+    return 0;
+}
+int orc_quat_rotate_inverse(const float *q, const float *v, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[3]; quat_rotate_s(q + 4 * i, v + 3 * i, t, 1); memcpy(o + 3 * i, t, 12); }
+    return 0;
+}
+int orc_slerp(const float *q0, const float *q1, const float *t, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float r[4]; slerp(q0 + 4 * i, q1 + 4 * i, t[i], r); memcpy(o + 4 * i, r, 16); }
+    return 0;
+}
+int orc_scale(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
+{
+    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); o[i] = 0.5f * (x[i] + 1.0f) * (hi[c] - lo[c]) + lo[c]; }
+    return 0;
+}
+int orc_unscale(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
+{
+    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); o[i] = unscale1(x[i], lo[c], hi[c]); }
+    return 0;
+}
+int orc_tensor_clamp(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
+{
+    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); o[i] = fmaxf(fminf(x[i], hi[c]), lo[c]); }
+    return 0;
+}
+int orc_quat_from_angle_axis(const float *angle, const float *axis, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[4]; quat_from_angle_axis(angle[i], axis + 3 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}
+int orc_normalize_angle(const float *x, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) o[i] = normalize_angle(x[i]);
+    return 0;
+}
+int orc_quat_to_exp_map(const float *q, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[3]; quat_to_exp_map(q + 4 * i, t); memcpy(o + 3 * i, t, 12); }
+    return 0;
+}
+int orc_exp_map_to_quat(const float *e, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[4]; exp_map_to_quat(e + 3 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}
+int orc_quat_to_tan_norm(const float *q, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[6]; quat_to_tan_norm(q + 4 * i, t); memcpy(o + 6 * i, t, 24); }
+    return 0;
+}
+int orc_calc_heading_quat_inv(const float *q, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[4]; calc_heading_quat_inv(q + 4 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}

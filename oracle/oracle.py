@@ -67,3 +67,36 @@ def ant_step(params, bufs, n):
 
 def humanoid_step(params, bufs, n):
     _call(lib().orc_humanoid_step, params, _abi.LocoBuffers, bufs, n)
+
+
+# ---- torch_jit_utils math: numpy in, numpy out ---------------------------
+_OUT_WIDTH = {"quat_mul": 4, "quat_conjugate": 4, "quat_rotate": 3, "quat_rotate_inverse": 3, "slerp": 4,
+              "quat_from_angle_axis": 4, "normalize_angle": 1, "quat_to_exp_map": 3, "exp_map_to_quat": 4,
+              "quat_to_tan_norm": 6, "calc_heading_quat_inv": 4}
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def rowwise(name, *inputs):
+    """Run orc_<name> on [n, w] float32 arrays; returns [n, out_width] (or [n])."""
+    ins = [_f32(a) for a in inputs]
+    n = ins[0].shape[0]
+    w = _OUT_WIDTH[name]
+    out = np.empty((n, w) if w > 1 else (n,), np.float32)
+    fn = getattr(lib(), "orc_" + name)
+    args = [C.c_void_p(a.ctypes.data) for a in ins] + [C.c_void_p(out.ctypes.data), C.c_int64(n)]
+    assert fn(*args) == 0
+    return out
+
+
+def affine(name, x, lower, upper):
+    """scale / unscale / tensor_clamp of x [n, d] against lower / upper [d]."""
+    x, lower, upper = _f32(x), _f32(lower), _f32(upper)
+    n, d = x.shape
+    out = np.empty_like(x)
+    fn = getattr(lib(), "orc_" + name)
+    assert fn(C.c_void_p(x.ctypes.data), C.c_void_p(lower.ctypes.data), C.c_void_p(upper.ctypes.data),
+              C.c_void_p(out.ctypes.data), C.c_int64(n), C.c_int32(d)) == 0
+    return out
