@@ -133,6 +133,74 @@ int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b,
                       int64_t n_envs, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * AllegroHand in-hand reorientation.
+ * Two entry points, as the reference splits the work (tasks/allegro_hand.py):
+ *  igx_allegro_pre_physics  = pre_physics_step :586-615 with reset_target_pose
+ *      :506-522, reset_idx :524-584 and randomize_rotation(_pen) :722-732
+ *      (resets happen BEFORE the physics step in this task);
+ *  igx_allegro_post_physics = post_physics_step :627-632 with
+ *      compute_observations :406-435, compute_full_state :462-504,
+ *      compute_full_observations :437-460 and compute_hand_reward :663-719,
+ *      including the cross-environment update of consecutive_successes.
+ * Actors per env in root_state_tensor: hand, object, goal (rows addressed by
+ * object_indices / goal_object_indices).  All 16 hand joints are actuated.
+ * ---------------------------------------------------------------------- */
+#define IGX_ALLEGRO_DOF 16
+#define IGX_ALLEGRO_OBS_FULL_NO_VEL 0 /* 50 columns */
+#define IGX_ALLEGRO_OBS_FULL 1        /* 72 columns */
+#define IGX_ALLEGRO_OBS_FULL_STATE 2  /* 88 columns (default) */
+#define IGX_ALLEGRO_RAND_PER_ENV 45   /* 4 goal-only draws, 37 env-reset draws, 4 goal draws inside the env reset */
+
+typedef struct igx_allegro_params {
+    int32_t obs_type;                  /* IGX_ALLEGRO_OBS_* */
+    int32_t max_consecutive_successes; /* env.maxConsecutiveSuccesses, 0 */
+    int32_t ignore_z_rot;              /* object_type == "pen" */
+    int32_t use_relative_control;      /* env.useRelativeControl */
+    float dist_reward_scale, rot_reward_scale, rot_eps, action_penalty_scale;
+    float success_tolerance;   /* already doubled for the pen */
+    float success_threshold_c; /* largest c with |2*asin(c)| <= success_tolerance in the caller's libm:
+                                  the success decision is taken on c = min(|quat_diff.xyz|, 1) */
+    float reach_goal_bonus, fall_dist, fall_penalty;
+    float max_episode_length_m1;
+    float av_factor, one_minus_av_factor; /* float32(av), float32(1.0 - double(float32(av))) */
+    float vel_obs_scale;          /* 0.2 */
+    float force_torque_obs_scale; /* 10.0 */
+    float reset_position_noise, reset_dof_pos_noise, reset_dof_vel_noise;
+    float act_moving_average, one_minus_act_moving_average;
+    float dof_speed_scale_dt;     /* dofSpeedScale * dt (relative control) */
+    float goal_displacement[3];   /* (-0.2, -0.06, 0.12) */
+    float dof_lower[IGX_ALLEGRO_DOF], dof_upper[IGX_ALLEGRO_DOF];
+    uint64_t seed, rng_offset;
+} igx_allegro_params;
+
+typedef struct igx_allegro_buffers {
+    float *dof_state;                 /* [N,16,2] in (post) / in-out (pre: reset envs) */
+    const float *dof_force;           /* [N,16]; needed for the 88-column layouts */
+    float *root_state_tensor;         /* [3N,13]; pre: object / goal rows rewritten on reset */
+    const int64_t *object_indices;    /* [N] rows of root_state_tensor */
+    const int64_t *goal_object_indices; /* [N] */
+    float *goal_states;               /* [N,13] */
+    const float *goal_init_state;     /* [N,13] */
+    const float *object_init_state;   /* [N,13] */
+    const float *actions;             /* [N,16] */
+    float *prev_targets, *cur_targets; /* [N,16] */
+    const float *rand;                /* [N,45] uniforms in [0,1); NULL = Philox */
+    float *obs;                       /* [N,50|72|88] out */
+    float *states;                    /* [N,88] out, asymmetric observations; may be NULL */
+    float *rew;                       /* [N] out */
+    int64_t *reset, *reset_goal, *progress; /* [N] in/out */
+    int64_t *randomize;               /* [N] += 1 in post; may be NULL */
+    float *successes;                 /* [N] in/out */
+    float *consecutive_successes;     /* [1] in/out */
+    void *workspace;                  /* 64 bytes, zero before the first call; the library re-zeroes it */
+} igx_allegro_buffers;
+
+int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
+                            int64_t n_envs, igx_stream_t stream);
+int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
+                             int64_t n_envs, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * torch_jit_utils math, one batched call per reference function
  * (utils/torch_jit_utils.py).  Quaternions are [n,4] xyzw, vectors [n,3],
  * all fp32 contiguous; `out` may alias an input of the same shape.

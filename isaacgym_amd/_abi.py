@@ -76,6 +76,39 @@ class LocoBuffers(_Struct):
                 ("reset", ptr), ("progress", ptr), ("randomize", ptr),
                 ("true_objective", ptr)]
 
+IGX_ALLEGRO_DOF = 16
+IGX_ALLEGRO_RAND_PER_ENV = 45
+ALLEGRO_OBS_TYPES = {"full_no_vel": 0, "full": 1, "full_state": 2}
+ALLEGRO_NUM_OBS = {0: 50, 1: 72, 2: 88}
+
+
+class AllegroParams(_Struct):
+    _fields_ = [("obs_type", i32), ("max_consecutive_successes", i32), ("ignore_z_rot", i32),
+                ("use_relative_control", i32),
+                ("dist_reward_scale", f32), ("rot_reward_scale", f32), ("rot_eps", f32),
+                ("action_penalty_scale", f32),
+                ("success_tolerance", f32), ("success_threshold_c", f32),
+                ("reach_goal_bonus", f32), ("fall_dist", f32), ("fall_penalty", f32),
+                ("max_episode_length_m1", f32),
+                ("av_factor", f32), ("one_minus_av_factor", f32),
+                ("vel_obs_scale", f32), ("force_torque_obs_scale", f32),
+                ("reset_position_noise", f32), ("reset_dof_pos_noise", f32), ("reset_dof_vel_noise", f32),
+                ("act_moving_average", f32), ("one_minus_act_moving_average", f32),
+                ("dof_speed_scale_dt", f32),
+                ("goal_displacement", f32 * 3),
+                ("dof_lower", f32 * IGX_ALLEGRO_DOF), ("dof_upper", f32 * IGX_ALLEGRO_DOF),
+                ("seed", u64), ("rng_offset", u64)]
+
+
+class AllegroBuffers(_Struct):
+    _fields_ = [("dof_state", ptr), ("dof_force", ptr), ("root_state_tensor", ptr),
+                ("object_indices", ptr), ("goal_object_indices", ptr),
+                ("goal_states", ptr), ("goal_init_state", ptr), ("object_init_state", ptr),
+                ("actions", ptr), ("prev_targets", ptr), ("cur_targets", ptr), ("rand", ptr),
+                ("obs", ptr), ("states", ptr), ("rew", ptr),
+                ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
+                ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr)]
+
 
 def make_buffers(cls, arrays, ptr_of):
     """Build a *Buffers struct from a name->array mapping.

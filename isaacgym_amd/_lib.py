@@ -24,6 +24,8 @@ SYMBOLS = {
     "igx_cartpole_step": _STEP_SIG,
     "igx_ant_step": _STEP_SIG,
     "igx_humanoid_step": _STEP_SIG,
+    "igx_allegro_pre_physics": _STEP_SIG,
+    "igx_allegro_post_physics": _STEP_SIG,
 }
 # batched torch_jit_utils math: (inputs..., out, n[, d], stream)
 _I64 = C.c_int64
@@ -85,11 +87,14 @@ def tensor_ptr(t, dtype=None):
 
 _I64_FIELDS = {"reset", "progress", "randomize", "reset_goal", "terminate", "motion_ids", "frame_idx0",
                "frame_idx1", "object_indices", "goal_object_indices", "env_ids"}
+_RAW_FIELDS = {"workspace"}  # opaque device scratch: any dtype
 _F64_FIELDS = {"motion_times"}
 
 
 def _ptr_checked(name):
     def f(t):
+        if name in _RAW_FIELDS:
+            return tensor_ptr(t)
         want = torch.int64 if name in _I64_FIELDS else torch.float64 if name in _F64_FIELDS else torch.float32
         return tensor_ptr(t, want)
     return f

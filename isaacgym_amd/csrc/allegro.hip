@@ -1,0 +1,469 @@
+// AllegroHand in-hand reorientation: pre_physics_step (goal / env resets and
+// the action -> joint-target path) and post_physics_step (observations,
+// compute_hand_reward, cross-environment consecutive_successes update).
+//
+// Both kernels give a wavefront a tile of 64 consecutive environments.
+// post: the tile's dof_state / dof_force / actions slices stream in with
+//   16-byte non-temporal loads and land in their final columns of the LDS image
+//   of the observation rows; lane i gathers its object's root row (indexed by
+//   object_indices) and its goal pose, writes the 24 (18) pose columns, and
+//   evaluates the reward from its own row; rows leave as whole lines.  The two
+//   global sums of compute_hand_reward are reduced per wave, added to a 16-byte
+//   workspace with one integer and one double atomic per wave (exact for the
+//   integer-valued success counts, hence order independent), and folded into
+//   consecutive_successes by a one-thread kernel that also re-zeroes the
+//   workspace.
+// pre: flagged environments are re-initialised one at a time by the whole wave
+//   (lane j = joint j), then the action path runs over the tile's [64,16]
+//   slab of targets with coalesced 16-byte accesses.
+//
+// Reference: IsaacGymEnvs/isaacgymenvs/tasks/allegro_hand.py:586-615, :506-584,
+// :722-732 (pre) and :627-632, :406-504, :663-719 (post).
+#include "igx_device.hpp"
+#include "igx_host.hpp"
+#include "igx_tile.hpp"
+
+namespace igx {
+
+constexpr int AD = IGX_ALLEGRO_DOF;
+constexpr float PI_F = 3.14159274f;  // float32(np.pi)
+
+template <int OBS>
+struct AllegroLayout {
+    static constexpr bool VEL = OBS != IGX_ALLEGRO_OBS_FULL_NO_VEL;
+    static constexpr bool FORCE = OBS == IGX_ALLEGRO_OBS_FULL_STATE;
+    static constexpr int C_POS = 0;
+    static constexpr int C_VEL = AD;                                  // if VEL
+    static constexpr int C_FORCE = 2 * AD;                            // if FORCE
+    static constexpr int C_POSE = AD * (1 + (VEL ? 1 : 0) + (FORCE ? 1 : 0));
+    static constexpr int POSE_W = VEL ? 24 : 18;                      // obj pose 7 (+ vel 6) + goal pose 7 + quat diff 4
+    static constexpr int C_ACT = C_POSE + POSE_W;
+    static constexpr int NOBS = C_ACT + AD;                           // 50 / 72 / 88
+};
+
+struct f2pair { float up, uv; };
+
+// j-th of this environment's 45 uniforms, mapped to torch_rand_float(-1, 1)
+__device__ __forceinline__ float allegro_draw(const igx_allegro_params &p, const igx_allegro_buffers &b, int64_t e, int j)
+{
+    float u;
+    if (b.rand) {
+        u = b.rand[e * IGX_ALLEGRO_RAND_PER_ENV + j];
+    } else {
+        float q[4];
+        philox_uniform4(p.seed, p.rng_offset, e, j >> 2, q);
+        const int a = j & 3;
+        u = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
+    }
+    return 2.0f * u + (-1.0f);
+}
+
+// :722-725 randomize_rotation
+__device__ __forceinline__ f4 randomize_rotation(float r0, float r1)
+{
+    return quat_mul(quat_from_angle_axis(r0 * PI_F, f3{1.0f, 0.0f, 0.0f}),
+                    quat_from_angle_axis(r1 * PI_F, f3{0.0f, 1.0f, 0.0f}));
+}
+
+// :728-732 randomize_rotation_pen (max_angle 0.3)
+__device__ __forceinline__ f4 randomize_rotation_pen(float r0)
+{
+    return quat_mul(quat_from_angle_axis(1.57079637f + r0 * 0.3f, f3{1.0f, 0.0f, 0.0f}),
+                    quat_from_angle_axis(r0 * PI_F, f3{0.0f, 0.0f, 1.0f}));
+}
+
+// :506-522 reset_target_pose for environment e, executed by one lane
+__device__ __forceinline__ void reset_target_pose(const igx_allegro_params &p, const igx_allegro_buffers &b, int64_t e,
+                                                  float r0, float r1)
+{
+    const f4 rot = randomize_rotation(r0, r1);
+    float *gs = b.goal_states + e * 13;
+    const float *gi = b.goal_init_state + e * 13;
+    float *row = b.root_state_tensor + b.goal_object_indices[e] * 13;
+    const float g0 = gi[0], g1 = gi[1], g2 = gi[2];
+    gs[0] = g0; gs[1] = g1; gs[2] = g2;
+    gs[3] = rot.x; gs[4] = rot.y; gs[5] = rot.z; gs[6] = rot.w;
+    row[0] = g0 + p.goal_displacement[0];
+    row[1] = g1 + p.goal_displacement[1];
+    row[2] = g2 + p.goal_displacement[2];
+    row[3] = rot.x; row[4] = rot.y; row[5] = rot.z; row[6] = rot.w;
+#pragma unroll
+    for (int i = 7; i < 13; ++i) row[i] = 0.0f;
+    b.reset_goal[e] = 0;
+}
+
+__global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
+                                                           int64_t n)
+{
+    __shared__ __align__(16) float s_prev[WAVE * AD];
+    __shared__ float s_lim[2 * AD];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
+    const bool live = lane < nvalid;
+    const int64_t e = base + lane;
+    if (lane < 2 * AD) s_lim[lane] = lane < AD ? p.dof_lower[lane] : p.dof_upper[lane - AD];
+
+    int64_t rst = 0, rg = 0;
+    if (live) {
+        rst = b.reset[e];
+        rg = b.reset_goal[e];
+    }
+    // the tile's slab of previous targets -> LDS (the reset below may overwrite rows)
+    const int count = nvalid * AD;
+    if (nvalid == WAVE) {
+        v4f r[AD / 4];
+        load_chunks<WAVE * AD / 4>(b.prev_targets + base * AD, r, lane);
+#pragma unroll
+        for (int it = 0; it < AD / 4; ++it) *reinterpret_cast<v4f *>(s_prev + 4 * (lane + it * WAVE)) = r[it];
+    } else {
+        for (int i = lane; i < count; i += WAVE) s_prev[i] = b.prev_targets[base * AD + i];
+    }
+    wave_sync();
+
+    // ---- resets (rare): goal-only resets first, then full environment resets,
+    // in the order the reference applies them
+    uint64_t goal_mask = __ballot(live && rg != 0);
+    uint64_t env_mask = __ballot(live && rst != 0);
+    if (lane == 0) {
+        uint64_t m = goal_mask;
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t ee = base + src;
+            reset_target_pose(p, b, ee, allegro_draw(p, b, ee, 0), allegro_draw(p, b, ee, 1));
+        }
+    }
+    while (env_mask) {
+        const int src = __builtin_ctzll(env_mask);
+        env_mask &= env_mask - 1;
+        const int64_t ee = base + src;
+        if (lane == 0) {  // target pose again (inside reset_idx), then the object actor
+            reset_target_pose(p, b, ee, allegro_draw(p, b, ee, 41), allegro_draw(p, b, ee, 42));
+            float *row = b.root_state_tensor + b.object_indices[ee] * 13;
+            const float *oi = b.object_init_state + ee * 13;
+            const float r0 = allegro_draw(p, b, ee, 4), r1 = allegro_draw(p, b, ee, 5), r2 = allegro_draw(p, b, ee, 6);
+            const float r3 = allegro_draw(p, b, ee, 7), r4 = allegro_draw(p, b, ee, 8);
+            row[0] = oi[0] + p.reset_position_noise * r0;
+            row[1] = oi[1] + p.reset_position_noise * r1;
+            row[2] = oi[2] + p.reset_position_noise * r2;
+            const f4 rot = p.ignore_z_rot ? randomize_rotation_pen(r3) : randomize_rotation(r3, r4);
+            row[3] = rot.x; row[4] = rot.y; row[5] = rot.z; row[6] = rot.w;
+#pragma unroll
+            for (int i = 7; i < 13; ++i) row[i] = 0.0f;
+            b.progress[ee] = 0;
+            b.reset[ee] = 0;
+            b.successes[ee] = 0.0f;
+        }
+        if (lane < AD) {  // hand joints: lane j = joint j
+            const int j = lane;
+            const float rp = allegro_draw(p, b, ee, 4 + 5 + j);
+            const float rv = allegro_draw(p, b, ee, 4 + 5 + AD + j);
+            const float delta_max = s_lim[AD + j] - 0.0f, delta_min = s_lim[j] - 0.0f;
+            const float rand_delta = delta_min + (delta_max - delta_min) * 0.5f * (rp + 1.0f);
+            const float pos = 0.0f + p.reset_dof_pos_noise * rand_delta;
+            const float vel = 0.0f + p.reset_dof_vel_noise * rv;
+            reinterpret_cast<v2f *>(b.dof_state + ee * (2 * AD))[j] = v2f{pos, vel};
+            s_prev[src * AD + j] = pos;  // prev_targets = cur_targets = pos, consumed by the action path below
+        }
+    }
+    wave_sync();
+
+    // ---- action path over the tile's slab (chunk k: env k/4, joints 4(k%4)..)
+    auto target = [&](float a, float prev, float lo, float hi) {
+        float c;
+        if (p.use_relative_control) {
+            c = tensor_clamp(prev + p.dof_speed_scale_dt * a, lo, hi);
+        } else {
+            c = scale(a, lo, hi);
+            c = p.act_moving_average * c + p.one_minus_act_moving_average * prev;
+            c = tensor_clamp(c, lo, hi);
+        }
+        return c;
+    };
+    if (nvalid == WAVE) {
+        v4f act[AD / 4];
+        load_chunks<WAVE * AD / 4>(b.actions + base * AD, act, lane);
+#pragma unroll
+        for (int it = 0; it < AD / 4; ++it) {
+            const int k = lane + it * WAVE;
+            const int j0 = 4 * (k & 3);
+            const v4f pv = *reinterpret_cast<const v4f *>(s_prev + 4 * k);
+            v4f c;
+            c.x = target(act[it].x, pv.x, s_lim[j0 + 0], s_lim[AD + j0 + 0]);
+            c.y = target(act[it].y, pv.y, s_lim[j0 + 1], s_lim[AD + j0 + 1]);
+            c.z = target(act[it].z, pv.z, s_lim[j0 + 2], s_lim[AD + j0 + 2]);
+            c.w = target(act[it].w, pv.w, s_lim[j0 + 3], s_lim[AD + j0 + 3]);
+            st_stream(reinterpret_cast<v4f *>(b.cur_targets + base * AD) + k, c);
+            st_stream(reinterpret_cast<v4f *>(b.prev_targets + base * AD) + k, c);
+        }
+    } else {
+        for (int i = lane; i < count; i += WAVE) {
+            const int j = i & (AD - 1);
+            const float c = target(b.actions[base * AD + i], s_prev[i], s_lim[j], s_lim[AD + j]);
+            b.cur_targets[base * AD + i] = c;
+            b.prev_targets[base * AD + i] = c;
+        }
+    }
+}
+
+struct AllegroWorkspace {
+    unsigned long long num_resets;
+    double finished;
+};
+
+template <int OBS, bool REWARD>
+__global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
+                                                            float *__restrict__ obs_out, int64_t n)
+{
+    using L = AllegroLayout<OBS>;
+    constexpr int NOBS = L::NOBS;
+    __shared__ __align__(16) float s_tile[WAVE * NOBS];
+    __shared__ __align__(16) float s_lim[2 * AD];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
+    const bool full = nvalid == WAVE;
+    const bool live = lane < nvalid;
+    const int64_t e = base + lane;
+    if (lane < 2 * AD) s_lim[lane] = lane < AD ? p.dof_lower[lane] : p.dof_upper[lane - AD];
+
+    // ---- loads
+    int64_t prog = 0, rst = 0, rg = 0, rnd = 0;
+    float succ = 0.0f;
+    float obj[13], goal[7];
+    v4f r_dof[AD * 2 / 4], r_force[AD / 4], r_act[AD / 4], r_goal[(WAVE * 13 / 4 + WAVE - 1) / WAVE];
+    if (live) {
+        if (REWARD) {
+            prog = ld_stream(b.progress + e);
+            rst = ld_stream(b.reset + e);
+            rg = ld_stream(b.reset_goal + e);
+            succ = ld_stream(b.successes + e);
+            if (b.randomize) rnd = ld_stream(b.randomize + e);
+        }
+        const float *orow = b.root_state_tensor + b.object_indices[e] * 13;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) obj[i] = orow[i];
+    }
+    if (full) {
+        load_chunks<WAVE * AD * 2 / 4>(b.dof_state + base * (2 * AD), r_dof, lane);
+        if (L::FORCE) load_chunks<WAVE * AD / 4>(b.dof_force + base * AD, r_force, lane);
+        load_chunks<WAVE * AD / 4>(b.actions + base * AD, r_act, lane);
+        load_chunks<WAVE * 13 / 4>(b.goal_states + base * 13, r_goal, lane);
+    }
+
+    // ---- goal rows: transpose through the (still empty) tile
+    park_rows<13>(r_goal, b.goal_states + base * 13, s_tile, nvalid, lane);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 7; ++i) goal[i] = s_tile[lane * 13 + i];
+    wave_sync();
+
+    // ---- stage pass-through columns
+    if (full) {
+        if constexpr (L::VEL) {
+            stage_dof_state<AD, NOBS, L::C_POS, L::C_VEL>(r_dof, s_tile, s_lim, p.vel_obs_scale, lane);
+        } else {  // positions only
+#pragma unroll
+            for (int it = 0; it < AD * 2 / 4; ++it) {
+                const int pr = 2 * (lane + it * WAVE);
+                const int env = pr / AD, j = pr - env * AD;
+                s_tile[env * NOBS + L::C_POS + j] = unscale(r_dof[it].x, s_lim[j], s_lim[AD + j]);
+                s_tile[env * NOBS + L::C_POS + j + 1] = unscale(r_dof[it].z, s_lim[j + 1], s_lim[AD + j + 1]);
+            }
+        }
+        if constexpr (L::FORCE) stage_rows<AD, L::C_FORCE, NOBS, true>(r_force, s_tile, p.force_torque_obs_scale, lane);
+        stage_rows<AD, L::C_ACT, NOBS, false>(r_act, s_tile, 1.0f, lane);
+    } else {
+        for (int i = lane; i < nvalid * AD; i += WAVE) {
+            const int env = i / AD, j = i - env * AD;
+            const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * AD + i];
+            s_tile[env * NOBS + L::C_POS + j] = unscale(pv.x, s_lim[j], s_lim[AD + j]);
+            if (L::VEL) s_tile[env * NOBS + L::C_VEL + j] = p.vel_obs_scale * pv.y;
+            if (L::FORCE) s_tile[env * NOBS + L::C_FORCE + j] = p.force_torque_obs_scale * b.dof_force[base * AD + i];
+            s_tile[env * NOBS + L::C_ACT + j] = b.actions[base * AD + i];
+        }
+    }
+    wave_sync();
+
+    // ---- per-env: pose columns and reward
+    int64_t resets = 0;
+    float fin = 0.0f;
+    if (live) {
+        float *row = s_tile + lane * NOBS;
+        const f4 orot{obj[3], obj[4], obj[5], obj[6]};
+        const f4 grot{goal[3], goal[4], goal[5], goal[6]};
+        const f4 qd = quat_mul(orot, quat_conjugate(grot));
+        float *c = row + L::C_POSE;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) c[i] = obj[i];
+        int k = 7;
+        if (L::VEL) {
+            c[7] = obj[7]; c[8] = obj[8]; c[9] = obj[9];
+            c[10] = p.vel_obs_scale * obj[10]; c[11] = p.vel_obs_scale * obj[11]; c[12] = p.vel_obs_scale * obj[12];
+            k = 13;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) c[k + i] = goal[i];
+        c[k + 7] = qd.x; c[k + 8] = qd.y; c[k + 9] = qd.z; c[k + 10] = qd.w;
+
+        if (REWARD) {  // :663-719 compute_hand_reward
+            prog += 1;
+            if (b.randomize) st_stream(b.randomize + e, rnd + 1);
+            const float goal_dist = norm3(f3{obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2]});
+            const float cc = fminf(norm3(f3{qd.x, qd.y, qd.z}), 1.0f);
+            const float rot_dist = 2.0f * asinf(cc);
+            const float dist_rew = goal_dist * p.dist_reward_scale;
+            const float rot_rew = 1.0f / (fabsf(rot_dist) + p.rot_eps) * p.rot_reward_scale;
+            float act[AD], sq[AD];
+            read_cols<AD, L::C_ACT, NOBS>(row, act);
+#pragma unroll
+            for (int j = 0; j < AD; ++j) sq[j] = act[j] * act[j];
+            const float action_penalty = row_sum<AD>(sq);
+            float reward = dist_rew + rot_rew + action_penalty * p.action_penalty_scale;
+            // |rot_dist| <= success_tolerance, decided on the asin argument
+            const bool success = cc <= p.success_threshold_c;
+            const int64_t goal_resets = success ? 1 : rg;
+            succ = succ + (float)goal_resets;
+            if (goal_resets == 1) reward = reward + p.reach_goal_bonus;
+            resets = rst;
+            if (goal_dist >= p.fall_dist) {
+                reward = reward + p.fall_penalty;
+                resets = 1;
+            }
+            if (p.max_consecutive_successes > 0) {
+                if (success) prog = 0;
+                if (succ >= (float)p.max_consecutive_successes) resets = 1;
+            }
+            const bool timed_out = (float)prog >= p.max_episode_length_m1;
+            if (timed_out) resets = 1;
+            if (p.max_consecutive_successes > 0 && timed_out) reward = reward + 0.5f * p.fall_penalty;
+            st_stream(b.rew + e, reward);
+            st_stream(b.reset + e, resets);
+            st_stream(b.reset_goal + e, goal_resets);
+            st_stream(b.progress + e, prog);
+            st_stream(b.successes + e, succ);
+            fin = succ * (float)resets;
+        }
+    }
+    if (REWARD) {  // wave-level partial sums -> workspace
+        float f = fin;
+        long long cnt = resets;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            f += __shfl_xor(f, off);
+            cnt += __shfl_xor(cnt, off);
+        }
+        if (lane == 0 && cnt != 0) {
+            AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
+            atomicAdd(&ws->num_resets, (unsigned long long)cnt);
+            atomicAdd(&ws->finished, (double)f);
+        }
+    }
+    wave_sync();
+    drain_rows<NOBS>(obs_out + base * NOBS, s_tile, nvalid, lane);
+    if (REWARD && OBS == IGX_ALLEGRO_OBS_FULL_STATE && b.states)  // asymmetric observations: same 88 columns
+        drain_rows<NOBS>(b.states + base * NOBS, s_tile, nvalid, lane);
+}
+
+// :714-719 consecutive_successes update from the two global sums
+__global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_allegro_buffers b)
+{
+    AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
+    const unsigned long long num_resets = ws->num_resets;
+    const float fin = (float)ws->finished;
+    if (num_resets > 0) {
+        const float cons = b.consecutive_successes[0];
+        b.consecutive_successes[0] = p.av_factor * fin / (float)(long long)num_resets + p.one_minus_av_factor * cons;
+    }
+    ws->num_resets = 0;
+    ws->finished = 0.0;
+}
+
+static int check_allegro(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, bool post,
+                         const char *who)
+{
+    if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "%s: n_envs %lld out of range", who, (long long)n);
+    if (p->obs_type < 0 || p->obs_type > 2) return fail(IGX_E_PARAM, "%s: unknown obs_type %d", who, p->obs_type);
+    if (n == 0) return IGX_OK;
+#define REQ(field, vec)                                                                   \
+    do {                                                                                  \
+        if (!b->field) return fail(IGX_E_NULL, "%s: %s is NULL", who, #field);            \
+        if (vec && !aligned16(b->field))                                                  \
+            return fail(IGX_E_ALIGN, "%s: %s must be 16-byte aligned", who, #field);      \
+    } while (0)
+    REQ(dof_state, true);
+    REQ(root_state_tensor, false);
+    REQ(object_indices, false);
+    REQ(goal_states, true);
+    REQ(actions, true);
+    REQ(reset, false);
+    REQ(reset_goal, false);
+    REQ(progress, false);
+    REQ(successes, false);
+    if (post) {
+        REQ(obs, true);
+        REQ(rew, false);
+        REQ(consecutive_successes, false);
+        REQ(workspace, true);
+        if (p->obs_type == IGX_ALLEGRO_OBS_FULL_STATE || b->states) REQ(dof_force, true);
+        if (b->states && !aligned16(b->states)) return fail(IGX_E_ALIGN, "%s: states must be 16-byte aligned", who);
+    } else {
+        REQ(goal_object_indices, false);
+        REQ(goal_init_state, false);
+        REQ(object_init_state, false);
+        REQ(prev_targets, true);
+        REQ(cur_targets, true);
+    }
+#undef REQ
+    return IGX_OK;
+}
+
+}  // namespace igx
+
+using namespace igx;
+
+extern "C" int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
+                                       igx_stream_t stream)
+{
+    int rc = check_allegro(p, b, n, false, "igx_allegro_pre_physics");
+    if (rc != IGX_OK || n == 0) return rc;
+    const int64_t tiles = (n + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(allegro_pre_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, static_cast<hipStream_t>(stream), *p,
+                       *b, n);
+    return launch_status("igx_allegro_pre_physics");
+}
+
+extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
+                                        igx_stream_t stream)
+{
+    int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics");
+    if (rc != IGX_OK || n == 0) return rc;
+    const unsigned tiles = (unsigned)((n + WAVE - 1) / WAVE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (p->obs_type) {
+    case IGX_ALLEGRO_OBS_FULL_NO_VEL:
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_NO_VEL, true>), dim3(tiles), dim3(WAVE), 0, s, *p, *b,
+                           b->obs, n);
+        break;
+    case IGX_ALLEGRO_OBS_FULL:
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL, true>), dim3(tiles), dim3(WAVE), 0, s, *p, *b,
+                           b->obs, n);
+        break;
+    default:
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, true>), dim3(tiles), dim3(WAVE), 0, s, *p, *b,
+                           b->obs, n);
+        break;
+    }
+    rc = launch_status("igx_allegro_post_physics");
+    if (rc != IGX_OK) return rc;
+    if (b->states && p->obs_type != IGX_ALLEGRO_OBS_FULL_STATE) {  // asymmetric critic state beside a smaller policy obs
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, false>), dim3(tiles), dim3(WAVE), 0, s, *p,
+                           *b, b->states, n);
+        rc = launch_status("igx_allegro_post_physics(states)");
+        if (rc != IGX_OK) return rc;
+    }
+    hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, s, *p, *b);
+    return launch_status("igx_allegro_post_physics(finalize)");
+}

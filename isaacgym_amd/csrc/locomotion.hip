@@ -29,22 +29,9 @@
 // (paths relative to IsaacGymEnvs/isaacgymenvs/).
 #include "igx_device.hpp"
 #include "igx_host.hpp"
+#include "igx_tile.hpp"
 
 namespace igx {
-
-constexpr int WAVE = 64;
-// native vectors: copies of these are real vector loads / stores (a struct
-// copy would become a memcpy through a private-memory temporary)
-using v4f = float __attribute__((ext_vector_type(4)));
-using v2f = float __attribute__((ext_vector_type(2)));
-
-// Streaming (non-temporal) global accesses: every byte of this path is touched
-// exactly once per step, so nothing is worth keeping in L2; on MI355X the nt
-// forms stream ~20 % faster than default-policy loads / stores here.
-template <class T>
-__device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
-template <class T>
-__device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
 
 template <int D, int S, bool HUM>
 struct LocoLayout {
@@ -64,143 +51,6 @@ struct LocoLayout {
     static constexpr int IT_ACT = (ACT4 + WAVE - 1) / WAVE;
     static constexpr int IT_DOF = (DOF4 + WAVE - 1) / WAVE;
 };
-
-// Compiler-level ordering point for the wave-synchronous LDS exchange.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int N4, int ITERS>
-__device__ __forceinline__ void load_chunks(const float *__restrict__ g, v4f (&v)[ITERS], int lane)
-{
-    const v4f *g4 = reinterpret_cast<const v4f *>(g);
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        // the last, partly filled round re-reads the final chunk in its idle
-        // lanes (same cache line, no extra traffic) so every load is unconditional
-        int k = lane + it * WAVE;
-        if ((it + 1) * WAVE > N4) k = (k < N4) ? k : N4 - 1;
-        v[it] = ld_stream(g4 + k);
-    }
-}
-
-// Rows of ROW floats -> columns C0.. of the LDS observation rows (optionally scaled).
-template <int ROW, int C0, int NOBS, bool SCALE, int ITERS>
-__device__ __forceinline__ void stage_rows(const v4f (&v)[ITERS], float *s_tile, float scl, int lane)
-{
-    constexpr int N4 = WAVE * ROW / 4;
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int k = lane + it * WAVE;
-        if ((it + 1) * WAVE <= N4 || k < N4) {
-            v4f x = v[it];
-            if (SCALE) { x.x *= scl; x.y *= scl; x.z *= scl; x.w *= scl; }
-            if constexpr (ROW % 4 == 0 && C0 % 4 == 0 && NOBS % 4 == 0) {
-                constexpr int R4 = ROW / 4;
-                const int env = k / R4, part = k - env * R4;
-                *reinterpret_cast<v4f *>(s_tile + env * NOBS + C0 + 4 * part) = x;
-            } else {
-                const float e[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int flat = 4 * k + i;
-                    const int env = flat / ROW, col = flat - env * ROW;
-                    s_tile[env * NOBS + C0 + col] = e[i];
-                }
-            }
-        }
-    }
-}
-
-// Interleaved (pos, vel) rows: position -> unscale -> column C_POS+j,
-// velocity * dof_vel_scale -> column C_VEL+j.
-template <int D, int NOBS, int C_POS, int C_VEL, int ITERS>
-__device__ __forceinline__ void stage_dof_state(const v4f (&v)[ITERS], float *s_tile, const float *s_lim,
-                                                float dof_vel_scale, int lane)
-{
-    constexpr int N4 = WAVE * D * 2 / 4;
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int k = lane + it * WAVE;
-        if ((it + 1) * WAVE <= N4 || k < N4) {
-            const v4f x = v[it];
-            const float pos[2] = {x.x, x.z}, vel[2] = {x.y, x.w};
-            if constexpr (D % 2 == 0 && C_POS % 2 == 0 && C_VEL % 2 == 0 && NOBS % 2 == 0) {
-                // both dofs of this chunk belong to one environment
-                const int pr = 2 * k;
-                const int env = pr / D, j = pr - env * D;
-                const v2f lo = *reinterpret_cast<const v2f *>(s_lim + j);
-                const v2f hi = *reinterpret_cast<const v2f *>(s_lim + D + j);
-                *reinterpret_cast<v2f *>(s_tile + env * NOBS + C_POS + j) =
-                    v2f{unscale(pos[0], lo.x, hi.x), unscale(pos[1], lo.y, hi.y)};
-                *reinterpret_cast<v2f *>(s_tile + env * NOBS + C_VEL + j) =
-                    v2f{vel[0] * dof_vel_scale, vel[1] * dof_vel_scale};
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int pr = 2 * k + h;
-                    const int env = pr / D, j = pr - env * D;
-                    s_tile[env * NOBS + C_POS + j] = unscale(pos[h], s_lim[j], s_lim[D + j]);
-                    s_tile[env * NOBS + C_VEL + j] = vel[h] * dof_vel_scale;
-                }
-            }
-        }
-    }
-}
-
-// torch.sum(dim=-1) over a row of D floats as the ATen CPU kernel orders it:
-// 8 vector lanes over the full blocks of 8, tail first, lanes left to right.
-template <int D>
-__device__ __forceinline__ float row_sum(const float (&x)[D])
-{
-    constexpr int NB = D / 8;
-    if constexpr (NB == 0) {
-        float r = x[0];
-#pragma unroll
-        for (int i = 1; i < D; ++i) r += x[i];
-        return r;
-    } else {
-        float lane[8];
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            float a = x[l];
-#pragma unroll
-            for (int b = 1; b < NB; ++b) a += x[8 * b + l];
-            lane[l] = a;
-        }
-        constexpr int T = 8 * NB;
-        float r;
-        if constexpr (T < D) {
-            r = x[T];
-#pragma unroll
-            for (int i = T + 1; i < D; ++i) r += x[i];
-            r += lane[0];
-        } else {
-            r = lane[0];
-        }
-#pragma unroll
-        for (int l = 1; l < 8; ++l) r += lane[l];
-        return r;
-    }
-}
-
-template <int LEN, int C0, int NOBS>
-__device__ __forceinline__ void read_cols(const float *row, float (&out)[LEN])
-{
-    if constexpr (LEN % 4 == 0 && C0 % 4 == 0 && NOBS % 4 == 0) {
-#pragma unroll
-        for (int i = 0; i < LEN / 4; ++i) {
-            const v4f v = *reinterpret_cast<const v4f *>(row + C0 + 4 * i);
-            out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < LEN; ++i) out[i] = row[C0 + i];
-    }
-}
 
 // reset_idx for the environments of this tile whose reset flag is set, one
 // environment at a time with the wave's lanes spread over the joints: lane j

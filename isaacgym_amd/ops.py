@@ -16,3 +16,11 @@ def ant_step(params, tensors, n_envs):
 
 def humanoid_step(params, tensors, n_envs):
     _lib.call_step("igx_humanoid_step", params, _abi.LocoBuffers, tensors, n_envs)
+
+
+def allegro_pre_physics(params, tensors, n_envs):
+    _lib.call_step("igx_allegro_pre_physics", params, _abi.AllegroBuffers, tensors, n_envs)
+
+
+def allegro_post_physics(params, tensors, n_envs):
+    _lib.call_step("igx_allegro_post_physics", params, _abi.AllegroBuffers, tensors, n_envs)

@@ -574,3 +574,194 @@ int orc_calc_heading_quat_inv(const float *q, float *o, int64_t n)
     for (int64_t i = 0; i < n; ++i) { float t[4]; calc_heading_quat_inv(q + 4 * i, t); memcpy(o + 4 * i, t, 16); }
     return 0;
 }
+
+/* ------------------------------------------------------- AllegroHand --- */
+#define PI_F 3.14159274f /* float32(np.pi) */
+
+/* tasks/allegro_hand.py:722-725 randomize_rotation */
+static void randomize_rotation(float r0, float r1, float o[4])
+{
+    const float xu[3] = { 1.0f, 0.0f, 0.0f }, yu[3] = { 0.0f, 1.0f, 0.0f };
+    float a[4], b[4];
+    quat_from_angle_axis(r0 * PI_F, xu, a);
+    quat_from_angle_axis(r1 * PI_F, yu, b);
+    quat_mul(a, b, o);
+}
+
+/* tasks/allegro_hand.py:728-732 randomize_rotation_pen (max_angle = 0.3) */
+static void randomize_rotation_pen(float r0, float o[4])
+{
+    const float xu[3] = { 1.0f, 0.0f, 0.0f }, zu[3] = { 0.0f, 0.0f, 1.0f };
+    float a[4], b[4];
+    quat_from_angle_axis(1.57079637f + r0 * 0.3f, xu, a);
+    quat_from_angle_axis(r0 * PI_F, zu, b);
+    quat_mul(a, b, o);
+}
+
+/* tasks/allegro_hand.py:506-522 reset_target_pose for one env */
+static void allegro_reset_target_pose(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t e,
+                                      float r0, float r1)
+{
+    float rot[4];
+    randomize_rotation(r0, r1, rot);
+    float *gs = b->goal_states + e * 13;
+    const float *gi = b->goal_init_state + e * 13;
+    for (int i = 0; i < 3; ++i) gs[i] = gi[i];
+    for (int i = 0; i < 4; ++i) gs[3 + i] = rot[i];
+    float *row = b->root_state_tensor + b->goal_object_indices[e] * 13;
+    for (int i = 0; i < 3; ++i) row[i] = gs[i] + p->goal_displacement[i];
+    for (int i = 0; i < 4; ++i) row[3 + i] = rot[i];
+    for (int i = 7; i < 13; ++i) row[i] = 0.0f;
+    b->reset_goal[e] = 0;
+}
+
+/* tasks/allegro_hand.py:586-615 pre_physics_step (+ :524-584 reset_idx) */
+int orc_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n)
+{
+    const int D = IGX_ALLEGRO_DOF, R = IGX_ALLEGRO_RAND_PER_ENV;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        const int rst = b->reset[e] != 0, rg = b->reset_goal[e] != 0;
+        float r[IGX_ALLEGRO_RAND_PER_ENV];
+        if (rst || rg)
+            for (int k = 0; k < R; ++k) /* torch_rand_float(-1, 1): (upper - lower) * u + lower */
+                r[k] = 2.0f * draw(b->rand, e, R, k, p->seed, p->rng_offset) + (-1.0f);
+        if (rg) allegro_reset_target_pose(p, b, e, r[0], r[1]);
+        if (rst) {
+            const float *rf = r + 4; /* the 37 floats of reset_idx */
+            allegro_reset_target_pose(p, b, e, r[41], r[42]);
+            float *row = b->root_state_tensor + b->object_indices[e] * 13;
+            const float *oi = b->object_init_state + e * 13;
+            for (int i = 0; i < 13; ++i) row[i] = oi[i];
+            row[0] = oi[0] + p->reset_position_noise * rf[0];
+            row[1] = oi[1] + p->reset_position_noise * rf[1];
+            row[2] = oi[2] + p->reset_position_noise * rf[2];
+            float rot[4];
+            if (p->ignore_z_rot) randomize_rotation_pen(rf[3], rot);
+            else randomize_rotation(rf[3], rf[4], rot);
+            for (int i = 0; i < 4; ++i) row[3 + i] = rot[i];
+            for (int i = 7; i < 13; ++i) row[i] = 0.0f;
+            for (int j = 0; j < D; ++j) {
+                float delta_max = p->dof_upper[j] - 0.0f, delta_min = p->dof_lower[j] - 0.0f;
+                float rand_delta = delta_min + (delta_max - delta_min) * 0.5f * (rf[5 + j] + 1.0f);
+                float pos = 0.0f + p->reset_dof_pos_noise * rand_delta;
+                b->dof_state[(e * D + j) * 2] = pos;
+                b->dof_state[(e * D + j) * 2 + 1] = 0.0f + p->reset_dof_vel_noise * rf[5 + D + j];
+                b->prev_targets[e * D + j] = pos;
+                b->cur_targets[e * D + j] = pos;
+            }
+            b->progress[e] = 0;
+            b->reset[e] = 0;
+            b->successes[e] = 0.0f;
+        }
+        for (int j = 0; j < D; ++j) {
+            float a = b->actions[e * D + j], lo = p->dof_lower[j], hi = p->dof_upper[j], c;
+            if (p->use_relative_control) {
+                c = b->prev_targets[e * D + j] + p->dof_speed_scale_dt * a;
+                c = fmaxf(fminf(c, hi), lo);
+            } else {
+                c = 0.5f * (a + 1.0f) * (hi - lo) + lo;
+                c = p->act_moving_average * c + p->one_minus_act_moving_average * b->prev_targets[e * D + j];
+                c = fmaxf(fminf(c, hi), lo);
+            }
+            b->cur_targets[e * D + j] = c;
+            b->prev_targets[e * D + j] = c;
+        }
+    }
+    return 0;
+}
+
+static void allegro_obs_row(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t e, int obs_type,
+                            const float *obj, const float *goal, const float qd[4], float *o)
+{
+    const int D = IGX_ALLEGRO_DOF;
+    const float *ds = b->dof_state + e * D * 2;
+    int c = 0;
+    for (int j = 0; j < D; ++j) o[c + j] = unscale1(ds[2 * j], p->dof_lower[j], p->dof_upper[j]);
+    c += D;
+    if (obs_type != IGX_ALLEGRO_OBS_FULL_NO_VEL) {
+        for (int j = 0; j < D; ++j) o[c + j] = p->vel_obs_scale * ds[2 * j + 1];
+        c += D;
+    }
+    if (obs_type == IGX_ALLEGRO_OBS_FULL_STATE) {
+        for (int j = 0; j < D; ++j) o[c + j] = p->force_torque_obs_scale * b->dof_force[e * D + j];
+        c += D;
+    }
+    for (int i = 0; i < 7; ++i) o[c + i] = obj[i];
+    c += 7;
+    if (obs_type != IGX_ALLEGRO_OBS_FULL_NO_VEL) {
+        for (int i = 0; i < 3; ++i) o[c + i] = obj[7 + i];
+        for (int i = 0; i < 3; ++i) o[c + 3 + i] = p->vel_obs_scale * obj[10 + i];
+        c += 6;
+    }
+    for (int i = 0; i < 7; ++i) o[c + i] = goal[i];
+    c += 7;
+    for (int i = 0; i < 4; ++i) o[c + i] = qd[i];
+    c += 4;
+    for (int j = 0; j < D; ++j) o[c + j] = b->actions[e * D + j];
+}
+
+/* tasks/allegro_hand.py:627-632 post_physics_step, :406-504 observations,
+ * :663-719 compute_hand_reward */
+int orc_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n)
+{
+    const int D = IGX_ALLEGRO_DOF;
+    const int nobs = p->obs_type == IGX_ALLEGRO_OBS_FULL_STATE ? 88 : p->obs_type == IGX_ALLEGRO_OBS_FULL ? 72 : 50;
+    int64_t num_resets = 0;
+    double fin = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : num_resets, fin)
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t prog = b->progress[e] + 1;
+        if (b->randomize) b->randomize[e] += 1;
+        const float *obj = b->root_state_tensor + b->object_indices[e] * 13;
+        const float *goal = b->goal_states + e * 13;
+        float gconj[4], qd[4];
+        quat_conjugate(goal + 3, gconj);
+        quat_mul(obj + 3, gconj, qd);
+        allegro_obs_row(p, b, e, p->obs_type, obj, goal, qd, b->obs + e * nobs);
+        if (b->states) allegro_obs_row(p, b, e, IGX_ALLEGRO_OBS_FULL_STATE, obj, goal, qd, b->states + e * 88);
+
+        /* compute_hand_reward */
+        float dpos[3] = { obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2] };
+        float goal_dist = norm3(dpos);
+        float cn = norm3(qd);
+        float cc = fminf(cn, 1.0f);
+        float rot_dist = 2.0f * asinf(cc);
+        float dist_rew = goal_dist * p->dist_reward_scale;
+        float rot_rew = 1.0f / (fabsf(rot_dist) + p->rot_eps) * p->rot_reward_scale;
+        float sq[IGX_ALLEGRO_DOF];
+        for (int j = 0; j < D; ++j) sq[j] = b->actions[e * D + j] * b->actions[e * D + j];
+        float action_penalty = row_sum(sq, D);
+        float reward = dist_rew + rot_rew + action_penalty * p->action_penalty_scale;
+        int success = cc <= p->success_threshold_c; /* == |rot_dist| <= success_tolerance */
+        int64_t goal_resets = success ? 1 : b->reset_goal[e];
+        float successes = b->successes[e] + (float)goal_resets;
+        if (goal_resets == 1) reward = reward + p->reach_goal_bonus;
+        int64_t resets = b->reset[e];
+        if (goal_dist >= p->fall_dist) {
+            reward = reward + p->fall_penalty;
+            resets = 1;
+        }
+        if (p->max_consecutive_successes > 0) {
+            if (success) prog = 0;
+            if (successes >= (float)p->max_consecutive_successes) resets = 1;
+        }
+        int timed_out = (float)prog >= p->max_episode_length_m1;
+        if (timed_out) resets = 1;
+        if (p->max_consecutive_successes > 0 && timed_out) reward = reward + 0.5f * p->fall_penalty;
+
+        b->rew[e] = reward;
+        b->reset[e] = resets;
+        b->reset_goal[e] = goal_resets;
+        b->progress[e] = prog;
+        b->successes[e] = successes;
+        num_resets += resets;
+        fin += (double)(successes * (float)resets);
+    }
+    if (num_resets > 0) {
+        float f = (float)fin;
+        b->consecutive_successes[0] =
+            p->av_factor * f / (float)num_resets + p->one_minus_av_factor * b->consecutive_successes[0];
+    }
+    return 0;
+}

@@ -69,6 +69,14 @@ def humanoid_step(params, bufs, n):
     _call(lib().orc_humanoid_step, params, _abi.LocoBuffers, bufs, n)
 
 
+def allegro_pre_physics(params, bufs, n):
+    _call(lib().orc_allegro_pre_physics, params, _abi.AllegroBuffers, bufs, n)
+
+
+def allegro_post_physics(params, bufs, n):
+    _call(lib().orc_allegro_post_physics, params, _abi.AllegroBuffers, bufs, n)
+
+
 # ---- torch_jit_utils math: numpy in, numpy out ---------------------------
 _OUT_WIDTH = {"quat_mul": 4, "quat_conjugate": 4, "quat_rotate": 3, "quat_rotate_inverse": 3, "slerp": 4,
               "quat_from_angle_axis": 4, "normalize_angle": 1, "quat_to_exp_map": 3, "exp_map_to_quat": 4,
