@@ -201,6 +201,107 @@ int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buff
                              int64_t n_envs, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * HumanoidAMP and the AMP motion library.  The character is the reference's
+ * 15-body / 28-dof AMP humanoid: DOF_BODY_IDS, DOF_OFFSETS and the four key
+ * bodies are fixed as in tasks/amp/humanoid_amp_base.py:43-49.
+ * ---------------------------------------------------------------------- */
+#define IGX_AMP_NUM_BODIES 15
+#define IGX_AMP_NUM_DOF 28
+#define IGX_AMP_NUM_KEY_BODIES 4
+#define IGX_AMP_OBS 105 /* 1 + 6 + 3 + 3 + 52 + 28 + 12 */
+
+/* Device-resident per-frame tables of every loaded motion, concatenated over
+ * motions (frame f of motion m is row frame_offset[m] + f).  Built once at
+ * load time by the host (tasks/amp/utils_amp/motion_lib.py:155-206, :248-324
+ * and the forward kinematics of poselib/skeleton/skeleton3d.py:431-472). */
+typedef struct igx_motion_tables {
+    int32_t num_motions;
+    int32_t reserved;
+    const double *motion_length;      /* [M] (F-1)/fps, fp64 as in the reference */
+    const double *motion_dt;          /* [M] 1/fps */
+    const int64_t *motion_num_frames; /* [M] */
+    const int64_t *frame_offset;      /* [M] */
+    const float *root_pos;            /* [sumF,3]   global_translation[:,0] */
+    const float *root_rot;            /* [sumF,4]   global_rotation[:,0] */
+    const float *local_rot;           /* [sumF,15,4] local_rotation */
+    const float *root_vel;            /* [sumF,3]   global_root_velocity */
+    const float *root_ang_vel;        /* [sumF,3]   global_root_angular_velocity */
+    const float *key_pos;             /* [sumF,4,3] global_translation[:, key_body_ids] */
+    const float *dof_vel;             /* [sumF,28]  dof_vels */
+} igx_motion_tables;
+
+typedef struct igx_motion_state_out { /* every pointer may be NULL to skip that output */
+    float *root_pos;      /* [n,3] */
+    float *root_rot;      /* [n,4] */
+    float *dof_pos;       /* [n,28] */
+    float *root_vel;      /* [n,3] */
+    float *root_ang_vel;  /* [n,3] */
+    float *dof_vel;       /* [n,28] */
+    float *key_pos;       /* [n,4,3] */
+    int64_t *frame_idx0;  /* [n] */
+    int64_t *frame_idx1;  /* [n] */
+    float *blend;         /* [n] */
+} igx_motion_state_out;
+
+/* MotionLib.get_motion_state (tasks/amp/utils_amp/motion_lib.py:83-153) with
+ * _calc_frame_blend (:233-241, fp64) and _local_rotation_to_dof (:265-293). */
+int igx_motion_state(const igx_motion_tables *t, const int64_t *motion_ids, const double *motion_times,
+                     int64_t n, const igx_motion_state_out *out, igx_stream_t stream);
+
+/* build_amp_observations (tasks/humanoid_amp.py:337-371) == compute_humanoid_observations
+ * (tasks/amp/humanoid_amp_base.py:542-576) with dof_to_obs (:510-540).
+ * root_states [n,13], dof_pos [n,28], dof_vel [n,28], key_body_pos [n,4,3] -> obs [n,105]. */
+int igx_amp_observations(const float *root_states, const float *dof_pos, const float *dof_vel,
+                         const float *key_body_pos, int32_t local_root_obs, float *obs, int64_t n,
+                         igx_stream_t stream);
+
+/* get_motion_state + build_amp_observations fused (HumanoidAMP.fetch_amp_obs_demo,
+ * tasks/humanoid_amp.py:146-171, and _init_amp_obs_ref :279-294): sample i is written
+ * to out + (out_rows ? out_rows[i] : i) * out_row_stride + out_col_offset (floats). */
+int igx_motion_amp_obs(const igx_motion_tables *t, const int64_t *motion_ids, const double *motion_times,
+                       int64_t n, int32_t local_root_obs, float *out, const int64_t *out_rows,
+                       int64_t out_row_stride, int64_t out_col_offset, igx_stream_t stream);
+
+typedef struct igx_amp_params {
+    int32_t num_amp_obs_steps;        /* env.numAMPObsSteps >= 2 */
+    int32_t local_root_obs;           /* env.localRootObs */
+    int32_t enable_early_termination; /* env.enableEarlyTermination */
+    int32_t num_contact_bodies;       /* <= 4 */
+    int32_t contact_body_ids[4];      /* feet: 11, 14 */
+    int32_t key_body_ids[4];          /* 5, 8, 11, 14 */
+    float termination_height;         /* 0.5 */
+    float max_episode_length_m1;      /* episodeLength - 1 */
+} igx_amp_params;
+
+typedef struct igx_amp_buffers {
+    float *root_states;             /* [N,13] */
+    float *dof_state;               /* [N,28,2] */
+    const float *rigid_body_state;  /* [N,15,13] */
+    const float *contact_forces;    /* [N,15,3] */
+    float *obs;                     /* [N,105] */
+    float *amp_obs;                 /* [N,K,105] newest first */
+    float *rew;                     /* [N] */
+    int64_t *reset, *terminate, *progress; /* [N] */
+} igx_amp_buffers;
+
+/* HumanoidAMP.post_physics_step (tasks/humanoid_amp.py:125-134 over
+ * tasks/amp/humanoid_amp_base.py:424-438): progress += 1, observations,
+ * reward (== 1), compute_humanoid_reset (:584-609), AMP history shift
+ * (:312-319) and current AMP observation (:321-330). */
+int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int64_t n_envs, igx_stream_t stream);
+
+/* reset_idx for env_ids [m] (tasks/humanoid_amp.py:184-204, :296-310 _set_env_state,
+ * tasks/amp/humanoid_amp_base.py:165-169): scatter the given per-env state rows
+ * (root_pos [m,3], root_rot [m,4], dof_pos [m,28], root_vel [m,3], root_ang_vel [m,3],
+ * dof_vel [m,28]) into root_states / dof_state, zero progress / reset / terminate,
+ * then recompute obs[env_ids] and amp_obs[env_ids, 0] from the (not yet refreshed)
+ * rigid_body_state, and copy it into every history slot (the _init_amp_obs_default
+ * behaviour; reference-state resets overwrite the history afterwards with
+ * igx_motion_amp_obs). */
+int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, const int64_t *env_ids, int64_t m,
+                           const igx_motion_state_out *state, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * torch_jit_utils math, one batched call per reference function
  * (utils/torch_jit_utils.py).  Quaternions are [n,4] xyzw, vectors [n,3],
  * all fp32 contiguous; `out` may alias an input of the same shape.

@@ -109,6 +109,36 @@ class AllegroBuffers(_Struct):
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
                 ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr)]
 
+IGX_AMP_NUM_BODIES = 15
+IGX_AMP_NUM_DOF = 28
+IGX_AMP_NUM_KEY_BODIES = 4
+IGX_AMP_OBS = 105
+
+
+class MotionTables(_Struct):
+    _fields_ = [("num_motions", i32), ("reserved", i32),
+                ("motion_length", ptr), ("motion_dt", ptr), ("motion_num_frames", ptr), ("frame_offset", ptr),
+                ("root_pos", ptr), ("root_rot", ptr), ("local_rot", ptr), ("root_vel", ptr),
+                ("root_ang_vel", ptr), ("key_pos", ptr), ("dof_vel", ptr)]
+
+
+class MotionStateOut(_Struct):
+    _fields_ = [("root_pos", ptr), ("root_rot", ptr), ("dof_pos", ptr), ("root_vel", ptr),
+                ("root_ang_vel", ptr), ("dof_vel", ptr), ("key_pos", ptr),
+                ("frame_idx0", ptr), ("frame_idx1", ptr), ("blend", ptr)]
+
+
+class AmpParams(_Struct):
+    _fields_ = [("num_amp_obs_steps", i32), ("local_root_obs", i32), ("enable_early_termination", i32),
+                ("num_contact_bodies", i32), ("contact_body_ids", i32 * 4), ("key_body_ids", i32 * 4),
+                ("termination_height", f32), ("max_episode_length_m1", f32)]
+
+
+class AmpBuffers(_Struct):
+    _fields_ = [("root_states", ptr), ("dof_state", ptr), ("rigid_body_state", ptr), ("contact_forces", ptr),
+                ("obs", ptr), ("amp_obs", ptr), ("rew", ptr), ("reset", ptr), ("terminate", ptr),
+                ("progress", ptr)]
+
 
 def make_buffers(cls, arrays, ptr_of):
     """Build a *Buffers struct from a name->array mapping.
@@ -121,7 +151,11 @@ def make_buffers(cls, arrays, ptr_of):
         if k not in names:
             raise KeyError("%s has no buffer named %r" % (cls.__name__, k))
     b = cls()
-    for n in names:
+    for n, ctype in cls._fields_:
+        if ctype is not ptr:
+            if n in arrays:
+                setattr(b, n, arrays[n])
+            continue
         a = arrays.get(n)
         setattr(b, n, None if a is None else ptr_of(a))
     return b

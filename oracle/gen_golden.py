@@ -614,7 +614,230 @@ def gen_allegro():
     _gen_allegro("ema", N=96, T=2, seed=9, act_moving_average=0.3)
 
 
-GENERATORS = {"allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+# --------------------------------------------------------------------------
+AMP_NODE_NAMES = ["pelvis", "torso", "head", "right_upper_arm", "right_lower_arm", "right_hand",
+                  "left_upper_arm", "left_lower_arm", "left_hand", "right_thigh", "right_shin", "right_foot",
+                  "left_thigh", "left_shin", "left_foot"]
+AMP_PARENTS = [-1, 0, 1, 1, 3, 4, 1, 6, 7, 0, 9, 10, 0, 12, 13]
+# plausible link offsets of a 15-body humanoid (the reference's t-pose file is a
+# pickle and is deliberately not loaded; the offsets only need to be non-trivial)
+AMP_LOCAL_T = [[0, 0, 0], [0, 0, 0.236], [0, 0, 0.224], [-0.024, -0.183, 0.243], [0, 0, -0.275], [0, 0, -0.259],
+               [-0.024, 0.183, 0.243], [0, 0, -0.275], [0, 0, -0.259], [0, -0.085, 0], [0, 0, -0.421],
+               [0, 0, -0.41], [0, 0.085, 0], [0, 0, -0.421], [0, 0, -0.41]]
+
+
+def _synth_motion(sk, tree, F, fps, seed):
+    """smooth random joint rotations + a wandering root, as a reference SkeletonMotion"""
+    rot3d = ref_shim.load("isaacgymenvs.tasks.amp.poselib.poselib.core.rotation3d")
+    g = torch.Generator().manual_seed(seed)
+    J = 15
+    tt = torch.arange(F, dtype=torch.float32).unsqueeze(-1) / fps
+    axis = torch.randn(J, 3, generator=g)
+    axis[[4, 7, 10, 13]] = torch.tensor([0.0, 1.0, 0.0])  # elbows / knees: hinge about y
+    axis = axis / axis.norm(dim=-1, keepdim=True)
+    amp = torch.rand(J, generator=g) * 1.2 + 0.1
+    w = torch.rand(J, generator=g) * 4 + 1
+    ph = torch.rand(J, generator=g) * 6.28
+    ang = amp * torch.sin(w * tt + ph)                    # [F, J]
+    half = ang.unsqueeze(-1) * 0.5
+    r = torch.cat([axis.unsqueeze(0) * torch.sin(half), torch.cos(half)], dim=-1)  # [F, J, 4]
+    r[0, 2] = torch.tensor([0.0, 0.0, 0.0, 1.0])          # an exact identity joint on frame 0
+    r = rot3d.quat_normalize(r)
+    root_t = torch.stack([0.8 * tt[:, 0], 0.3 * torch.sin(1.3 * tt[:, 0]), 0.9 + 0.05 * torch.sin(3 * tt[:, 0])], dim=-1)
+    state = sk.SkeletonState.from_rotation_and_root_translation(tree, r, root_t, is_local=True)
+    return sk.SkeletonMotion.from_skeleton_state(state, fps=fps)
+
+
+def gen_motion(seed=11):
+    _install_gym_stubs()
+    import tempfile
+    sk = ref_shim.load("isaacgymenvs.tasks.amp.poselib.poselib.skeleton.skeleton3d")
+    ml = ref_shim.load("isaacgymenvs.tasks.amp.utils_amp.motion_lib")
+    hamp = ref_shim.load("isaacgymenvs.tasks.humanoid_amp")
+    tree = sk.SkeletonTree(AMP_NODE_NAMES, torch.tensor(AMP_PARENTS), torch.tensor(AMP_LOCAL_T, dtype=torch.float32))
+    specs = [(90, 30, 1.0), (61, 60, 3.0)]  # (frames, fps, weight)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        entries = []
+        for i, (F, fps, wgt) in enumerate(specs):
+            m = _synth_motion(sk, tree, F, fps, seed + i)
+            m.to_file(os.path.join(d, "m%d.npy" % i))
+            entries.append({"file": "m%d.npy" % i, "weight": wgt})
+            out["m%d_rotation" % i] = m.rotation.numpy().copy()
+            out["m%d_root_translation" % i] = m.root_translation.numpy().copy()
+            out["m%d_global_velocity" % i] = m.global_velocity.numpy().copy()
+            out["m%d_global_angular_velocity" % i] = m.global_angular_velocity.numpy().copy()
+        with open(os.path.join(d, "set.yaml"), "w") as f:
+            yaml.safe_dump({"motions": entries}, f)
+        cwd = os.getcwd()
+        os.chdir("/")
+        lib = ml.MotionLib(motion_file=os.path.join(d, "set.yaml"), num_dofs=28,
+                           key_body_ids=np.array([5, 8, 11, 14]), device="cpu")
+        os.chdir(cwd)
+    for i, m in enumerate(lib._motions):
+        out["m%d_global_translation" % i] = m.global_translation.numpy().copy()
+        out["m%d_global_rotation" % i] = m.global_rotation.numpy().copy()
+        out["m%d_local_rotation" % i] = m.local_rotation.numpy().copy()
+        out["m%d_dof_vels" % i] = np.asarray(m.dof_vels, np.float64).copy()
+    out["parent_indices"] = np.array(AMP_PARENTS, np.int64)
+    out["local_translation"] = np.array(AMP_LOCAL_T, np.float32)
+    out["motion_lengths"] = lib._motion_lengths.copy()
+    out["motion_weights"] = lib._motion_weights.copy()
+    out["motion_dt"] = lib._motion_dt.copy()
+    out["motion_num_frames"] = lib._motion_num_frames.copy()
+    out["motion_fps"] = np.asarray(lib._motion_fps, np.float64).copy()
+
+    # sampling is host numpy RNG: pin it
+    np.random.seed(1234)
+    ids = lib.sample_motions(600)
+    times = lib.sample_time(ids)
+    out["sampled_ids"], out["sampled_times"] = ids.copy(), times.copy()
+    # edge cases: t = 0, t = len, beyond both ends, exact frame boundaries, history steps before the clip start
+    extra_ids = np.array([0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1], np.int64)
+    L = lib._motion_lengths
+    extra_t = np.array([0.0, L[0], -0.05, L[0] + 0.5, 0.0, L[1], -1e-9, 10.0, 3.0 / 30.0, 7.0 / 60.0,
+                        L[0] - 1e-12, 1.0 / 60.0 - 1e-15])
+    ids = np.concatenate([ids, extra_ids])
+    times = np.concatenate([times, extra_t])
+    out["ids"], out["times"] = ids, times
+    i0, i1, blend = lib._calc_frame_blend(times, lib._motion_lengths[ids], lib._motion_num_frames[ids],
+                                          lib._motion_dt[ids])
+    out["frame_idx0"], out["frame_idx1"], out["blend"] = i0.astype(np.int64), i1.astype(np.int64), blend
+    names = ["root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "key_pos"]
+    res = lib.get_motion_state(ids, times)
+    for k, v in zip(names, res):
+        out[k] = v.numpy().copy()
+    root_states = torch.cat([res[0], res[1], res[3], res[4]], dim=-1)
+    for lro in (False, True):
+        out["amp_obs_local%d" % int(lro)] = hamp.build_amp_observations(root_states, res[2], res[5], res[6], lro).numpy()
+    out["meta"] = _meta(task="MotionLib", seed=seed, specs=specs, np_seed=1234, key_body_ids=[5, 8, 11, 14])
+    np.savez_compressed(os.path.join(OUT, "motion.npz"), **out)
+    print("motion.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+    _gen_amp_task(lib, hamp, seed)
+
+
+def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4):
+    """HumanoidAMP.post_physics_step / reset_idx of the reference task class on
+    synthetic simulator tensors, with the reference MotionLib built above."""
+    cfg = _cfg("HumanoidAMP")
+    e = cfg["env"]
+    g = torch.Generator().manual_seed(seed + 50)
+
+    class Fake(hamp.HumanoidAMP):
+        def __init__(self):
+            pass
+
+    t = Fake()
+    t.cfg = cfg
+    t.device = "cpu"
+    t.num_envs = N
+    t.num_dof, t.num_bodies = 28, 15
+    t.gym, t.sim, t.viewer, t.debug_viz = _Any(), None, None, False
+    t.max_episode_length = e["episodeLength"]
+    t._local_root_obs = e["localRootObs"]
+    t._termination_height = e["terminationHeight"]
+    t._enable_early_termination = e["enableEarlyTermination"]
+    t._state_init = hamp.HumanoidAMP.StateInit[e["stateInit"]]
+    t._hybrid_init_prob = e["hybridInitProb"]
+    t._num_amp_obs_steps = K
+    t.dt = e["controlFrequencyInv"] * cfg["sim"]["dt"]
+    t._reset_default_env_ids, t._reset_ref_env_ids = [], []
+    t._motion_lib = lib
+    t._key_body_ids = torch.tensor([5, 8, 11, 14])
+    t._contact_body_ids = torch.tensor([11, 14])
+    t._root_states = torch.zeros(N, 13)
+    t._initial_root_states = torch.zeros(N, 13)
+    t._dof_state = torch.zeros(N * 28, 2)
+    t._dof_pos = t._dof_state.view(N, 28, 2)[..., 0]
+    t._dof_vel = t._dof_state.view(N, 28, 2)[..., 1]
+    t._initial_dof_pos = torch.zeros(N, 28)
+    t._initial_dof_vel = torch.zeros(N, 28)
+    t._rigid_body_state = torch.zeros(N * 15, 13)
+    t._rigid_body_pos = t._rigid_body_state.view(N, 15, 13)[..., 0:3]
+    t._contact_forces = torch.zeros(N, 15, 3)
+    t._terminate_buf = torch.ones(N, dtype=torch.long)
+    t.obs_buf = torch.zeros(N, 105)
+    t.rew_buf = torch.zeros(N)
+    t.reset_buf = torch.ones(N, dtype=torch.long)
+    t.progress_buf = torch.zeros(N, dtype=torch.long)
+    t.extras = {}
+    t.num_amp_obs = K * 105
+    t.actions = torch.zeros(N, 28)
+    t._amp_obs_buf = torch.zeros(N, K, 105)
+    t._curr_amp_obs_buf = t._amp_obs_buf[:, 0]
+    t._hist_amp_obs_buf = t._amp_obs_buf[:, 1:]
+
+    def physics():
+        root = torch.zeros(N, 13)
+        root[:, 0:3] = torch.randn(N, 3, generator=g) * 0.3
+        root[:, 2] = 0.9 + 0.1 * torch.randn(N, generator=g)
+        q = torch.randn(N, 4, generator=g)
+        root[:, 3:7] = q / q.norm(dim=-1, keepdim=True)
+        root[0, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+        root[:, 7:13] = torch.randn(N, 6, generator=g)
+        t._root_states.copy_(root)
+        ds = torch.randn(N, 28, 2, generator=g)
+        ds[:, :, 0] *= 1.2
+        ds[1, 0:3, 0] = 0.0          # zero exponential map: the masked 0/0 lanes
+        ds[2, 0:3, 0] = torch.tensor([1e-7, 0.0, 0.0])
+        ds[3, 0:3, 0] = torch.tensor([3.5, 1.0, 0.5])   # angle > pi
+        t._dof_state.copy_(ds.view(N * 28, 2))
+        rb = torch.randn(N, 15, 13, generator=g)
+        rb[:, :, 0:3] = root[:, None, 0:3] + 0.4 * torch.randn(N, 15, 3, generator=g)
+        rb[:, :, 2] = 0.45 + 0.6 * torch.rand(N, 15, generator=g)  # a few bodies below the 0.5 m threshold
+        t._rigid_body_state.copy_(rb.view(N * 15, 13))
+        cf = torch.randn(N, 15, 3, generator=g) * 0.03          # below the 0.1 threshold ...
+        hit = torch.rand(N, generator=g) < 0.3                  # ... except one body of ~30 % of the envs
+        body = torch.randint(0, 15, (N,), generator=g)
+        cf[hit, body[hit], 0] = 0.5
+        cf[:, [11, 14]] = 5.0                                   # feet always in contact
+        cf[4] = -3.0                                            # negative components never count
+        cf[5, 3, 1] = 0.1                                       # exactly 0.1: not > 0.1
+        t._contact_forces.copy_(cf)
+
+    keys = ["in_root", "in_dof_state", "in_rigid_body_state", "in_contact_forces", "obs", "amp_obs", "rew", "reset",
+            "terminate", "progress"]
+    rec = {k: [] for k in keys}
+    rst = {}
+    for step in range(T):
+        if step == 1:
+            t.progress_buf[:4] = torch.tensor([296, 297, 298, 299])
+        if step == 2:
+            # reset_done(): reset_idx on the flagged envs, Random state init (motion library)
+            env_ids = t.reset_buf.nonzero(as_tuple=False).flatten()
+            rst["env_ids"] = env_ids.numpy().copy()
+            np.random.seed(777)
+            t.reset_idx(env_ids)
+            rst["motion_ids"] = np.asarray(t._reset_ref_motion_ids).copy()
+            rst["motion_times"] = np.asarray(t._reset_ref_motion_times).copy()
+            for k, v in (("root", t._root_states), ("dof_state", t._dof_state), ("obs", t.obs_buf),
+                         ("amp_obs", t._amp_obs_buf), ("progress", t.progress_buf), ("reset", t.reset_buf),
+                         ("terminate", t._terminate_buf)):
+                rst["after_" + k] = v.numpy().copy()
+        physics()
+        rec["in_root"].append(t._root_states.numpy().copy())
+        rec["in_dof_state"].append(t._dof_state.numpy().copy())
+        rec["in_rigid_body_state"].append(t._rigid_body_state.numpy().copy())
+        rec["in_contact_forces"].append(t._contact_forces.numpy().copy())
+        t.post_physics_step()
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["amp_obs"].append(t.extras["amp_obs"].numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["terminate"].append(t.extras["terminate"].numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update({"reset_" + k: v for k, v in rst.items()})
+    out["meta"] = _meta(task="HumanoidAMP", N=N, K=K, T=T, seed=seed, dt=t.dt, local_root_obs=bool(t._local_root_obs),
+                        termination_height=t._termination_height, max_episode_length=t.max_episode_length,
+                        enable_early_termination=bool(t._enable_early_termination), reset_before_step=2,
+                        np_seed=777, state_init=e["stateInit"])
+    np.savez_compressed(os.path.join(OUT, "amp.npz"), **out)
+    print("amp.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+          "terminated", int(out["terminate"].sum()), "resets", int(out["reset"].sum()))
+
+
+GENERATORS = {"motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -765,3 +765,211 @@ int orc_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buff
     }
     return 0;
 }
+
+/* ------------------------------------------ AMP motion library / obs --- */
+/* tasks/amp/humanoid_amp_base.py:43-44 */
+static const int DOF_BODY_IDS[12] = { 1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 13, 14 };
+static const int DOF_OFFSETS[13] = { 0, 3, 6, 9, 10, 13, 14, 17, 18, 21, 24, 25, 28 };
+
+/* tasks/amp/utils_amp/motion_lib.py:233-241 _calc_frame_blend, all fp64 */
+static void calc_frame_blend(double time, double len, int64_t num_frames, double dt, int64_t *i0, int64_t *i1,
+                             double *blend)
+{
+    double phase = time / len;
+    if (phase < 0.0) phase = 0.0;
+    if (phase > 1.0) phase = 1.0;
+    int64_t f0 = (int64_t)(phase * (double)(num_frames - 1)); /* astype(int): truncation */
+    int64_t f1 = f0 + 1 < num_frames - 1 ? f0 + 1 : num_frames - 1;
+    *i0 = f0; *i1 = f1;
+    *blend = (time - (double)f0 * dt) / dt;
+}
+
+/* one sample of MotionLib.get_motion_state (:83-153) + _local_rotation_to_dof (:265-293) */
+static void motion_state_one(const igx_motion_tables *t, int64_t id, double time, float root_pos[3],
+                             float root_rot[4], float dof_pos[28], float root_vel[3], float root_ang_vel[3],
+                             float dof_vel[28], float key_pos[12], int64_t *fi0, int64_t *fi1, float *fblend)
+{
+    int64_t i0, i1;
+    double bl;
+    calc_frame_blend(time, t->motion_length[id], t->motion_num_frames[id], t->motion_dt[id], &i0, &i1, &bl);
+    const float blend = (float)bl; /* to_torch(..., dtype=float) */
+    const int64_t r0 = t->frame_offset[id] + i0, r1 = t->frame_offset[id] + i1;
+    const float omb = 1.0f - blend;
+    for (int i = 0; i < 3; ++i) root_pos[i] = omb * t->root_pos[r0 * 3 + i] + blend * t->root_pos[r1 * 3 + i];
+    slerp(t->root_rot + r0 * 4, t->root_rot + r1 * 4, blend, root_rot);
+    for (int i = 0; i < 12; ++i) key_pos[i] = omb * t->key_pos[r0 * 12 + i] + blend * t->key_pos[r1 * 12 + i];
+    for (int i = 0; i < 3; ++i) {
+        root_vel[i] = t->root_vel[r0 * 3 + i];
+        root_ang_vel[i] = t->root_ang_vel[r0 * 3 + i];
+    }
+    for (int i = 0; i < 28; ++i) dof_vel[i] = t->dof_vel[r0 * 28 + i];
+    for (int j = 0; j < 12; ++j) {
+        const int body = DOF_BODY_IDS[j], off = DOF_OFFSETS[j], size = DOF_OFFSETS[j + 1] - off;
+        float q[4];
+        slerp(t->local_rot + (r0 * 15 + body) * 4, t->local_rot + (r1 * 15 + body) * 4, blend, q);
+        if (size == 3) {
+            quat_to_exp_map(q, dof_pos + off);
+        } else {
+            float theta, axis[3];
+            quat_to_angle_axis(q, &theta, axis);
+            theta = theta * axis[1]; /* joint assumed to turn about y */
+            dof_pos[off] = normalize_angle(theta);
+        }
+    }
+    if (fi0) *fi0 = i0;
+    if (fi1) *fi1 = i1;
+    if (fblend) *fblend = blend;
+}
+
+int orc_motion_state(const igx_motion_tables *t, const int64_t *ids, const double *times, int64_t n,
+                     const igx_motion_state_out *o)
+{
+    for (int64_t s = 0; s < n; ++s) {
+        float rp[3], rr[4], dp[28], rv[3], rav[3], dv[28], kp[12], bl;
+        int64_t i0, i1;
+        motion_state_one(t, ids[s], times[s], rp, rr, dp, rv, rav, dv, kp, &i0, &i1, &bl);
+        if (o->root_pos) memcpy(o->root_pos + s * 3, rp, 12);
+        if (o->root_rot) memcpy(o->root_rot + s * 4, rr, 16);
+        if (o->dof_pos) memcpy(o->dof_pos + s * 28, dp, 112);
+        if (o->root_vel) memcpy(o->root_vel + s * 3, rv, 12);
+        if (o->root_ang_vel) memcpy(o->root_ang_vel + s * 3, rav, 12);
+        if (o->dof_vel) memcpy(o->dof_vel + s * 28, dv, 112);
+        if (o->key_pos) memcpy(o->key_pos + s * 12, kp, 48);
+        if (o->frame_idx0) o->frame_idx0[s] = i0;
+        if (o->frame_idx1) o->frame_idx1[s] = i1;
+        if (o->blend) o->blend[s] = bl;
+    }
+    return 0;
+}
+
+/* tasks/humanoid_amp.py:337-371 build_amp_observations for one character */
+static void amp_obs_one(const float root_pos[3], const float root_rot[4], const float root_vel[3],
+                        const float root_ang_vel[3], const float *dof_pos, int dof_pos_stride, const float *dof_vel,
+                        int dof_vel_stride, const float key_pos[12], int local_root_obs, float obs[105])
+{
+    float heading_rot[4], rro[4];
+    calc_heading_quat_inv(root_rot, heading_rot);
+    if (local_root_obs) quat_mul(heading_rot, root_rot, rro);
+    else memcpy(rro, root_rot, 16);
+    obs[0] = root_pos[2];
+    quat_to_tan_norm(rro, obs + 1);
+    quat_rotate_s(heading_rot, root_vel, obs + 7, 0);
+    quat_rotate_s(heading_rot, root_ang_vel, obs + 10, 0);
+    int c = 13;
+    for (int j = 0; j < 12; ++j) { /* humanoid_amp_base.py:510-540 dof_to_obs */
+        const int off = DOF_OFFSETS[j], size = DOF_OFFSETS[j + 1] - off;
+        if (size == 3) {
+            float e[3] = { dof_pos[off * dof_pos_stride], dof_pos[(off + 1) * dof_pos_stride],
+                           dof_pos[(off + 2) * dof_pos_stride] };
+            float q[4];
+            exp_map_to_quat(e, q);
+            quat_to_tan_norm(q, obs + c);
+            c += 6;
+        } else {
+            obs[c] = dof_pos[off * dof_pos_stride];
+            c += 1;
+        }
+    }
+    for (int j = 0; j < 28; ++j) obs[c + j] = dof_vel[j * dof_vel_stride];
+    c += 28;
+    for (int k = 0; k < 4; ++k) {
+        float d[3] = { key_pos[3 * k] - root_pos[0], key_pos[3 * k + 1] - root_pos[1], key_pos[3 * k + 2] - root_pos[2] };
+        quat_rotate_s(heading_rot, d, obs + c + 3 * k, 0);
+    }
+}
+
+int orc_amp_observations(const float *root_states, const float *dof_pos, const float *dof_vel,
+                         const float *key_body_pos, int32_t local_root_obs, float *obs, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float *r = root_states + i * 13;
+        amp_obs_one(r, r + 3, r + 7, r + 10, dof_pos + i * 28, 1, dof_vel + i * 28, 1, key_body_pos + i * 12,
+                    local_root_obs, obs + i * 105);
+    }
+    return 0;
+}
+
+int orc_motion_amp_obs(const igx_motion_tables *t, const int64_t *ids, const double *times, int64_t n,
+                       int32_t local_root_obs, float *out, const int64_t *out_rows, int64_t out_row_stride,
+                       int64_t out_col_offset)
+{
+    for (int64_t s = 0; s < n; ++s) {
+        float rp[3], rr[4], dp[28], rv[3], rav[3], dv[28], kp[12];
+        motion_state_one(t, ids[s], times[s], rp, rr, dp, rv, rav, dv, kp, NULL, NULL, NULL);
+        float *o = out + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset;
+        amp_obs_one(rp, rr, rv, rav, dp, 1, dv, 1, kp, local_root_obs, o);
+    }
+    return 0;
+}
+
+/* observation of environment e from the simulator tensors */
+static void amp_env_obs(const igx_amp_params *p, const igx_amp_buffers *b, int64_t e, float obs[105])
+{
+    const float *r = b->root_states + e * 13;
+    const float *ds = b->dof_state + e * 56;
+    float key[12];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 3; ++i) key[3 * k + i] = b->rigid_body_state[(e * 15 + p->key_body_ids[k]) * 13 + i];
+    amp_obs_one(r, r + 3, r + 7, r + 10, ds, 2, ds + 1, 2, key, p->local_root_obs, obs);
+}
+
+/* tasks/humanoid_amp.py:125-134 over tasks/amp/humanoid_amp_base.py:424-438, :584-609 */
+int orc_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int64_t n)
+{
+    const int K = p->num_amp_obs_steps;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t prog = b->progress[e] + 1;
+        float obs[105];
+        amp_env_obs(p, b, e, obs);
+        memcpy(b->obs + e * 105, obs, sizeof obs);
+        b->rew[e] = 1.0f;
+        int64_t terminated = 0;
+        if (p->enable_early_termination) {
+            int fall_contact = 0, fall_height = 0;
+            for (int body = 0; body < 15; ++body) {
+                int is_contact_body = 0;
+                for (int c = 0; c < p->num_contact_bodies; ++c) is_contact_body |= p->contact_body_ids[c] == body;
+                if (is_contact_body) continue;
+                const float *cf = b->contact_forces + (e * 15 + body) * 3;
+                if (cf[0] > 0.1f || cf[1] > 0.1f || cf[2] > 0.1f) fall_contact = 1;
+                if (b->rigid_body_state[(e * 15 + body) * 13 + 2] < p->termination_height) fall_height = 1;
+            }
+            if (fall_contact && fall_height && prog > 1) terminated = 1;
+        }
+        b->reset[e] = ((float)prog >= p->max_episode_length_m1) ? 1 : terminated;
+        b->terminate[e] = terminated;
+        b->progress[e] = prog;
+        float *a = b->amp_obs + e * K * 105;
+        for (int k = K - 2; k >= 0; --k) memcpy(a + (k + 1) * 105, a + k * 105, 105 * sizeof(float));
+        memcpy(a, obs, sizeof obs);
+    }
+    return 0;
+}
+
+/* tasks/humanoid_amp.py:184-204, :296-310, :274-277 (see include/igx.h) */
+int orc_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, const int64_t *env_ids, int64_t m,
+                           const igx_motion_state_out *s)
+{
+    const int K = p->num_amp_obs_steps;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t e = env_ids[i];
+        float *r = b->root_states + e * 13;
+        if (s->root_pos) memcpy(r, s->root_pos + i * 3, 12);
+        if (s->root_rot) memcpy(r + 3, s->root_rot + i * 4, 16);
+        if (s->root_vel) memcpy(r + 7, s->root_vel + i * 3, 12);
+        if (s->root_ang_vel) memcpy(r + 10, s->root_ang_vel + i * 3, 12);
+        for (int j = 0; j < 28; ++j) {
+            if (s->dof_pos) b->dof_state[(e * 28 + j) * 2] = s->dof_pos[i * 28 + j];
+            if (s->dof_vel) b->dof_state[(e * 28 + j) * 2 + 1] = s->dof_vel[i * 28 + j];
+        }
+        b->progress[e] = 0;
+        b->reset[e] = 0;
+        b->terminate[e] = 0;
+        float obs[105];
+        amp_env_obs(p, b, e, obs);
+        memcpy(b->obs + e * 105, obs, sizeof obs);
+        for (int k = 0; k < K; ++k) memcpy(b->amp_obs + (e * K + k) * 105, obs, sizeof obs);
+    }
+    return 0;
+}

@@ -77,6 +77,62 @@ def allegro_post_physics(params, bufs, n):
     _call(lib().orc_allegro_post_physics, params, _abi.AllegroBuffers, bufs, n)
 
 
+# ---- AMP motion library / observations ------------------------------------
+def motion_tables(tabs):
+    """tabs: dict of numpy arrays named like igx_motion_tables fields."""
+    t = _abi.make_buffers(_abi.MotionTables, tabs, _np_ptr)
+    t.num_motions = len(tabs["motion_length"])
+    return t
+
+
+def motion_state(tabs, ids, times):
+    ids = np.ascontiguousarray(ids, np.int64)
+    times = np.ascontiguousarray(times, np.float64)
+    n = len(ids)
+    out = dict(root_pos=np.zeros((n, 3), np.float32), root_rot=np.zeros((n, 4), np.float32),
+               dof_pos=np.zeros((n, 28), np.float32), root_vel=np.zeros((n, 3), np.float32),
+               root_ang_vel=np.zeros((n, 3), np.float32), dof_vel=np.zeros((n, 28), np.float32),
+               key_pos=np.zeros((n, 4, 3), np.float32), frame_idx0=np.zeros(n, np.int64),
+               frame_idx1=np.zeros(n, np.int64), blend=np.zeros(n, np.float32))
+    t = motion_tables(tabs)
+    o = _abi.make_buffers(_abi.MotionStateOut, out, _np_ptr)
+    assert lib().orc_motion_state(C.byref(t), C.c_void_p(ids.ctypes.data), C.c_void_p(times.ctypes.data),
+                                  C.c_int64(n), C.byref(o)) == 0
+    return out
+
+
+def amp_observations(root_states, dof_pos, dof_vel, key_body_pos, local_root_obs):
+    rs, dp, dv, kp = (_f32(a) for a in (root_states, dof_pos, dof_vel, key_body_pos))
+    n = rs.shape[0]
+    obs = np.zeros((n, 105), np.float32)
+    assert lib().orc_amp_observations(*[C.c_void_p(a.ctypes.data) for a in (rs, dp, dv, kp)],
+                                      C.c_int32(int(local_root_obs)), C.c_void_p(obs.ctypes.data), C.c_int64(n)) == 0
+    return obs
+
+
+def motion_amp_obs(tabs, ids, times, local_root_obs, out, out_rows=None, out_row_stride=105, out_col_offset=0):
+    ids = np.ascontiguousarray(ids, np.int64)
+    times = np.ascontiguousarray(times, np.float64)
+    t = motion_tables(tabs)
+    rows = None if out_rows is None else np.ascontiguousarray(out_rows, np.int64)
+    assert lib().orc_motion_amp_obs(C.byref(t), C.c_void_p(ids.ctypes.data), C.c_void_p(times.ctypes.data),
+                                    C.c_int64(len(ids)), C.c_int32(int(local_root_obs)),
+                                    C.c_void_p(_np_ptr(out)), C.c_void_p(rows.ctypes.data if rows is not None else None),
+                                    C.c_int64(out_row_stride), C.c_int64(out_col_offset)) == 0
+
+
+def humanoid_amp_step(params, bufs, n):
+    _call(lib().orc_humanoid_amp_step, params, _abi.AmpBuffers, bufs, n)
+
+
+def humanoid_amp_reset(params, bufs, env_ids, state):
+    env_ids = np.ascontiguousarray(env_ids, np.int64)
+    b = _abi.make_buffers(_abi.AmpBuffers, bufs, _np_ptr)
+    s = _abi.make_buffers(_abi.MotionStateOut, state, _np_ptr)
+    assert lib().orc_humanoid_amp_reset(C.byref(params), C.byref(b), C.c_void_p(env_ids.ctypes.data),
+                                        C.c_int64(len(env_ids)), C.byref(s)) == 0
+
+
 # ---- torch_jit_utils math: numpy in, numpy out ---------------------------
 _OUT_WIDTH = {"quat_mul": 4, "quat_conjugate": 4, "quat_rotate": 3, "quat_rotate_inverse": 3, "slerp": 4,
               "quat_from_angle_axis": 4, "normalize_angle": 1, "quat_to_exp_map": 3, "exp_map_to_quat": 4,

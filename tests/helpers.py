@@ -184,3 +184,118 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         # reward: -10*dist + 1/(|rot_dist|+0.1) (+250 bonus): natural scale 1
         assert_close(to_np(b["rew"]), g["rew"][t], what=what + "rew")
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
+
+
+def motion_tabs_from_golden(g):
+    """igx_motion_tables (numpy) from the reference's per-frame tables in motion.npz."""
+    M = len(g["motion_lengths"])
+    cat = lambda key, f: np.ascontiguousarray(np.concatenate([f(g["m%d_%s" % (i, key)]) for i in range(M)]),  # noqa: E731
+                                               np.float32)
+    kb = g["meta"]["key_body_ids"]
+    nf = g["motion_num_frames"].astype(np.int64)
+    return dict(
+        motion_length=np.ascontiguousarray(g["motion_lengths"], np.float64),
+        motion_dt=np.ascontiguousarray(g["motion_dt"], np.float64),
+        motion_num_frames=nf,
+        frame_offset=np.concatenate([[0], np.cumsum(nf)[:-1]]).astype(np.int64),
+        root_pos=cat("global_translation", lambda a: a[:, 0]),
+        root_rot=cat("global_rotation", lambda a: a[:, 0]),
+        local_rot=cat("local_rotation", lambda a: a),
+        root_vel=cat("global_velocity", lambda a: a[:, 0]),
+        root_ang_vel=cat("global_angular_velocity", lambda a: a[:, 0]),
+        key_pos=cat("global_translation", lambda a: a[:, kb]),
+        dof_vel=cat("dof_vels", lambda a: a))
+
+
+def check_motion_state(got, g, what=""):
+    """got: dict of numpy arrays named like igx_motion_state_out."""
+    # frame indices and the fp64 blend (rounded to fp32) are exact
+    assert np.array_equal(got["frame_idx0"], g["frame_idx0"]), what + "frame_idx0"
+    assert np.array_equal(got["frame_idx1"], g["frame_idx1"]), what + "frame_idx1"
+    assert np.array_equal(got["blend"], g["blend"].astype(np.float32)), what + "blend"
+    # gathers and lerps are plain IEEE arithmetic: exact
+    for k in ("root_pos", "root_vel", "root_ang_vel", "dof_vel", "key_pos"):
+        assert bit_equal_fraction(got[k].reshape(g[k].shape), g[k]) == 1.0, what + k
+    # slerp / quaternion -> dof go through acos / sin / atan2: 1e-5 class
+    assert_close(got["root_rot"], g["root_rot"], what=what + "root_rot")
+    assert_close(got["dof_pos"], g["dof_pos"], scale=np.pi, what=what + "dof_pos")
+
+
+def amp_params(meta):
+    return _abi.AmpParams(num_amp_obs_steps=meta["K"], local_root_obs=int(meta["local_root_obs"]),
+                          enable_early_termination=int(meta["enable_early_termination"]), num_contact_bodies=2,
+                          contact_body_ids=[11, 14, 0, 0], key_body_ids=[5, 8, 11, 14],
+                          termination_height=meta["termination_height"],
+                          max_episode_length_m1=float(meta["max_episode_length"] - 1))
+
+
+def amp_replay(g, fns, to_buf, to_np, zeros):
+    """Replay amp.npz.  fns: dict with step(p, bufs, n), reset(p, bufs, env_ids, state),
+    motion_state(ids, times) -> dict of backend buffers, motion_amp_obs(ids, times, lro, out, rows, stride, off)."""
+    m = g["meta"]
+    N, K, T = m["N"], m["K"], m["T"]
+    p = amp_params(m)
+    b = dict(root_states=zeros((N, 13), np.float32), dof_state=zeros((N, 28, 2), np.float32),
+             rigid_body_state=zeros((N, 15, 13), np.float32), contact_forces=zeros((N, 15, 3), np.float32),
+             obs=zeros((N, 105), np.float32), amp_obs=zeros((N, K, 105), np.float32), rew=zeros((N,), np.float32),
+             reset=to_buf(np.ones(N, np.int64)), terminate=to_buf(np.ones(N, np.int64)),
+             progress=zeros((N,), np.int64))
+
+    def put(name, arr):
+        dst = b[name]
+        src = to_buf(np.ascontiguousarray(arr).reshape(tuple(dst.shape)))
+        if hasattr(dst, "copy_"):
+            dst.copy_(src)
+        else:
+            dst[...] = src
+
+    for t in range(T):
+        if t == 1:
+            prog = to_np(b["progress"]).copy()
+            prog[:4] = [296, 297, 298, 299]
+            put("progress", prog)
+        if t == m["reset_before_step"]:
+            env_ids = g["reset_env_ids"]
+            assert np.array_equal(np.nonzero(to_np(b["reset"]))[0], env_ids)
+            ids, times = g["reset_motion_ids"], g["reset_motion_times"]
+            state = fns["motion_state"](ids, times)
+            fns["reset"](p, b, env_ids, state)
+            # history slots from the motion at t - dt * (k + 1)   (humanoid_amp.py:279-294)
+            hist_ids = np.tile(np.expand_dims(ids, -1), [1, K - 1]).flatten()
+            hist_t = (np.expand_dims(times, -1) + (-m["dt"] * (np.arange(0, K - 1) + 1))).flatten()
+            rows = (np.expand_dims(env_ids, -1) * K + 1 + np.arange(0, K - 1)).flatten().astype(np.int64)
+            fns["motion_amp_obs"](hist_ids, hist_t, p.local_root_obs, b["amp_obs"], rows, 105, 0)
+            for k in ("progress", "reset", "terminate"):
+                assert np.array_equal(to_np(b[k]), g["reset_after_" + k]), "after reset: " + k
+            root = to_np(b["root_states"])
+            assert_close(root, g["reset_after_root"], what="after reset: root_states")
+            assert_close(to_np(b["dof_state"]).reshape(-1, 2), g["reset_after_dof_state"], scale=np.pi,
+                         what="after reset: dof_state")
+            # continue from the reference's own state so the comparison of the derived
+            # observations is not conditioned on library-level differences in slerp
+            put("root_states", g["reset_after_root"])
+            put("dof_state", g["reset_after_dof_state"])
+            obs = to_np(b["obs"])
+            mask = np.zeros(N, bool)
+            mask[env_ids] = True
+            assert_close(obs[mask], g["reset_after_obs"][mask], scale=np.pi, rtol=2e-5, what="after reset: obs")
+            assert_close(to_np(b["amp_obs"])[mask], g["reset_after_amp_obs"][mask], scale=np.pi, rtol=2e-5,
+                         what="after reset: amp_obs")
+            put("obs", g["reset_after_obs"])
+            put("amp_obs", g["reset_after_amp_obs"])
+        put("root_states", g["in_root"][t])
+        put("dof_state", g["in_dof_state"][t])
+        put("rigid_body_state", g["in_rigid_body_state"][t])
+        put("contact_forces", g["in_contact_forces"][t])
+        fns["step"](p, b, N)
+        what = "step %d " % t
+        for k in ("reset", "terminate", "progress"):
+            assert np.array_equal(to_np(b[k]), g[k][t]), what + k
+        assert np.array_equal(to_np(b["rew"]), g["rew"][t]), what + "rew"
+        assert_close(to_np(b["obs"]), g["obs"][t], what=what + "obs")
+        amp = to_np(b["amp_obs"]).reshape(N, K * 105)
+        assert_close(amp[:, :105], g["amp_obs"][t][:, :105], what=what + "amp_obs current")
+        if t != m["reset_before_step"] and t > 0:
+            # history = previous step's current slot, bit for bit
+            assert np.array_equal(amp[:, 105:210], prev_curr), what + "amp_obs history"
+        prev_curr = amp[:, :105].copy()
