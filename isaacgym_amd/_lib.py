@@ -27,6 +27,14 @@ SYMBOLS = {
     "igx_allegro_pre_physics": _STEP_SIG,
     "igx_allegro_post_physics": _STEP_SIG,
 }
+# AMP motion library / HumanoidAMP
+SYMBOLS.update({
+    "igx_motion_state": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
+    "igx_amp_observations": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int64, _P]),
+    "igx_motion_amp_obs": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, C.c_int64, _P]),
+    "igx_humanoid_amp_step": _STEP_SIG,
+    "igx_humanoid_amp_reset": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
+})
 # batched torch_jit_utils math: (inputs..., out, n[, d], stream)
 _I64 = C.c_int64
 for _name, _nin in (("igx_quat_mul", 2), ("igx_quat_conjugate", 1), ("igx_quat_rotate", 2),

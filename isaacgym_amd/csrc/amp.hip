@@ -1,0 +1,483 @@
+// HumanoidAMP step / reset and the AMP motion library.
+//
+//  igx_motion_state      MotionLib.get_motion_state: 16 lanes per sample (12
+//                        dof joints, root, key bodies, 2 x dof velocities); the
+//                        frame index / blend arithmetic is fp64 in the
+//                        reference's operation order, so indices are exact.
+//  igx_motion_amp_obs    the same sampling fused with build_amp_observations:
+//                        every lane writes its own observation columns, the
+//                        interpolated state never touches memory.
+//  igx_amp_observations  build_amp_observations on given state arrays.
+//  igx_humanoid_amp_step post_physics_step: a wavefront owns 64 environments;
+//                        root rows and the dof_state slab stream in through
+//                        LDS, lane i computes environment i's 105 observation
+//                        columns into the LDS tile, contact forces stream
+//                        through a predicate, body heights / key-body positions
+//                        are gathered per lane; the observation rows and the
+//                        shifted AMP history leave as whole contiguous lines.
+//  igx_humanoid_amp_reset reset_idx: scatter of sampled reference states and
+//                        recomputation of the touched rows (one lane per env).
+//
+// Reference: IsaacGymEnvs/isaacgymenvs/tasks/humanoid_amp.py:125-134, :146-171,
+// :184-204, :279-330, :337-371; tasks/amp/humanoid_amp_base.py:424-438,
+// :510-609; tasks/amp/utils_amp/motion_lib.py:83-153, :233-241, :265-293.
+#include "igx_device.hpp"
+#include "igx_host.hpp"
+#include "igx_tile.hpp"
+
+namespace igx {
+
+constexpr int NB = IGX_AMP_NUM_BODIES;   // 15
+constexpr int ND = IGX_AMP_NUM_DOF;      // 28
+constexpr int NK = IGX_AMP_NUM_KEY_BODIES;
+constexpr int NO = IGX_AMP_OBS;          // 105
+
+// tasks/amp/humanoid_amp_base.py:43-44
+__device__ constexpr int DOF_BODY_IDS[12] = {1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 13, 14};
+__device__ constexpr int DOF_OFFSETS[13] = {0, 3, 6, 9, 10, 13, 14, 17, 18, 21, 24, 25, 28};
+// first dof_obs column of joint j (6 columns for a 3-dof joint, 1 for a hinge)
+__device__ constexpr int DOF_OBS_OFFSETS[12] = {0, 6, 12, 18, 19, 25, 26, 32, 33, 39, 45, 46};
+
+struct FrameBlend {
+    int64_t r0, r1;  // table rows of the two frames
+    int64_t i0, i1;  // frame indices within the motion
+    float blend;
+};
+
+// tasks/amp/utils_amp/motion_lib.py:233-241 _calc_frame_blend (fp64 throughout)
+__device__ __forceinline__ FrameBlend calc_frame_blend(const igx_motion_tables &t, int64_t id, double time)
+{
+    const double len = t.motion_length[id], dt = t.motion_dt[id];
+    const int64_t nf = t.motion_num_frames[id];
+    double phase = time / len;
+    phase = phase < 0.0 ? 0.0 : phase;  // np.clip(phase, 0, 1)
+    phase = phase > 1.0 ? 1.0 : phase;
+    FrameBlend f;
+    f.i0 = (int64_t)(phase * (double)(nf - 1));  // astype(int): truncation
+    f.i1 = f.i0 + 1 < nf - 1 ? f.i0 + 1 : nf - 1;
+    f.blend = (float)((time - (double)f.i0 * dt) / dt);
+    const int64_t off = t.frame_offset[id];
+    f.r0 = off + f.i0;
+    f.r1 = off + f.i1;
+    return f;
+}
+
+__device__ __forceinline__ f4 load_q(const float *p) { return f4{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ f3 load_v(const float *p) { return f3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ f3 lerp3(f3 a, f3 b, float blend)
+{
+    const float omb = 1.0f - blend;  // (1.0 - blend) * x0 + blend * x1
+    return f3{omb * a.x + blend * b.x, omb * a.y + blend * b.y, omb * a.z + blend * b.z};
+}
+
+// dof position(s) of joint j from its interpolated local rotation
+// (motion_lib.py:265-293 _local_rotation_to_dof); returns the joint size
+__device__ __forceinline__ int joint_dof(f4 q, int j, float (&d)[3])
+{
+    const int size = DOF_OFFSETS[j + 1] - DOF_OFFSETS[j];
+    if (size == 3) {
+        const f3 e = quat_to_exp_map(q);
+        d[0] = e.x; d[1] = e.y; d[2] = e.z;
+    } else {
+        float theta;
+        f3 axis;
+        quat_to_angle_axis(q, theta, axis);
+        d[0] = normalize_angle(theta * axis.y);  // joint assumed to turn about y
+    }
+    return size;
+}
+
+// dof_to_obs for one joint (humanoid_amp_base.py:510-540): returns #columns
+__device__ __forceinline__ int joint_obs(const float (&d)[3], int size, float (&o)[6])
+{
+    if (size == 3) {
+        const f4 q = exp_map_to_quat(f3{d[0], d[1], d[2]});
+        const f3 t = quat_rotate<false>(q, f3{1.0f, 0.0f, 0.0f});
+        const f3 n = quat_rotate<false>(q, f3{0.0f, 0.0f, 1.0f});
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = n.x; o[4] = n.y; o[5] = n.z;
+        return 6;
+    }
+    o[0] = d[0];
+    return 1;
+}
+
+// root part of build_amp_observations (humanoid_amp.py:337-356): columns 0..12
+__device__ __forceinline__ void root_obs(f3 root_pos, f4 root_rot, f3 root_vel, f3 root_ang_vel, bool local_root_obs,
+                                         f4 &heading_rot, float (&o)[13])
+{
+    heading_rot = calc_heading_quat_inv(root_rot);
+    const f4 rro = local_root_obs ? quat_mul(heading_rot, root_rot) : root_rot;
+    const f3 t = quat_rotate<false>(rro, f3{1.0f, 0.0f, 0.0f});
+    const f3 n = quat_rotate<false>(rro, f3{0.0f, 0.0f, 1.0f});
+    const f3 lv = quat_rotate<false>(heading_rot, root_vel);
+    const f3 la = quat_rotate<false>(heading_rot, root_ang_vel);
+    o[0] = root_pos.z;
+    o[1] = t.x; o[2] = t.y; o[3] = t.z; o[4] = n.x; o[5] = n.y; o[6] = n.z;
+    o[7] = lv.x; o[8] = lv.y; o[9] = lv.z;
+    o[10] = la.x; o[11] = la.y; o[12] = la.z;
+}
+
+// ---------------------------------------------------------------- motion state
+// 16 work items per sample: 0..11 dof joints, 12 root, 13 key bodies, 14/15 dof velocities
+template <bool AMP_OBS>
+__global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, const int64_t *__restrict__ ids,
+                                                     const double *__restrict__ times, int64_t n,
+                                                     const igx_motion_state_out o, int local_root_obs,
+                                                     float *__restrict__ obs, const int64_t *__restrict__ out_rows,
+                                                     int64_t out_row_stride, int64_t out_col_offset)
+{
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t s = gid >> 4;
+    const int item = (int)(gid & 15);
+    if (s >= n) return;
+    const int64_t id = ids[s];
+    const FrameBlend f = calc_frame_blend(t, id, times[s]);
+    float *orow = AMP_OBS ? obs + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset : nullptr;
+
+    if (item < 12) {
+        const int j = item, body = DOF_BODY_IDS[j];
+        const f4 q = slerp(load_q(t.local_rot + (f.r0 * NB + body) * 4), load_q(t.local_rot + (f.r1 * NB + body) * 4),
+                           f.blend);
+        float d[3];
+        const int size = joint_dof(q, j, d);
+        if (AMP_OBS) {
+            float c[6];
+            joint_obs(d, size, c);
+            float *dst = orow + 13 + DOF_OBS_OFFSETS[j];
+            dst[0] = c[0];
+            if (size == 3) { dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3]; dst[4] = c[4]; dst[5] = c[5]; }
+        } else if (o.dof_pos) {
+            float *dst = o.dof_pos + s * ND + DOF_OFFSETS[j];
+            dst[0] = d[0];
+            if (size == 3) { dst[1] = d[1]; dst[2] = d[2]; }
+        }
+    } else if (item == 12 || item == 13) {
+        const f3 root_pos = lerp3(load_v(t.root_pos + f.r0 * 3), load_v(t.root_pos + f.r1 * 3), f.blend);
+        const f4 root_rot = slerp(load_q(t.root_rot + f.r0 * 4), load_q(t.root_rot + f.r1 * 4), f.blend);
+        if (item == 12) {
+            const f3 rv = load_v(t.root_vel + f.r0 * 3), rav = load_v(t.root_ang_vel + f.r0 * 3);
+            if (AMP_OBS) {
+                f4 heading_rot;
+                float c[13];
+                root_obs(root_pos, root_rot, rv, rav, local_root_obs != 0, heading_rot, c);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) orow[i] = c[i];
+            } else {
+                if (o.root_pos) { o.root_pos[s * 3] = root_pos.x; o.root_pos[s * 3 + 1] = root_pos.y; o.root_pos[s * 3 + 2] = root_pos.z; }
+                if (o.root_rot) { o.root_rot[s * 4] = root_rot.x; o.root_rot[s * 4 + 1] = root_rot.y; o.root_rot[s * 4 + 2] = root_rot.z; o.root_rot[s * 4 + 3] = root_rot.w; }
+                if (o.root_vel) { o.root_vel[s * 3] = rv.x; o.root_vel[s * 3 + 1] = rv.y; o.root_vel[s * 3 + 2] = rv.z; }
+                if (o.root_ang_vel) { o.root_ang_vel[s * 3] = rav.x; o.root_ang_vel[s * 3 + 1] = rav.y; o.root_ang_vel[s * 3 + 2] = rav.z; }
+                if (o.frame_idx0) o.frame_idx0[s] = f.i0;
+                if (o.frame_idx1) o.frame_idx1[s] = f.i1;
+                if (o.blend) o.blend[s] = f.blend;
+            }
+        } else {
+            const f4 heading_rot = AMP_OBS ? calc_heading_quat_inv(root_rot) : f4{0, 0, 0, 1};
+            for (int k = 0; k < NK; ++k) {
+                const f3 kp = lerp3(load_v(t.key_pos + (f.r0 * NK + k) * 3), load_v(t.key_pos + (f.r1 * NK + k) * 3), f.blend);
+                if (AMP_OBS) {
+                    const f3 l = quat_rotate<false>(heading_rot, f3{kp.x - root_pos.x, kp.y - root_pos.y, kp.z - root_pos.z});
+                    orow[93 + 3 * k] = l.x; orow[94 + 3 * k] = l.y; orow[95 + 3 * k] = l.z;
+                } else if (o.key_pos) {
+                    o.key_pos[(s * NK + k) * 3] = kp.x; o.key_pos[(s * NK + k) * 3 + 1] = kp.y; o.key_pos[(s * NK + k) * 3 + 2] = kp.z;
+                }
+            }
+        }
+    } else {
+        const int h = item - 14;  // velocities are not interpolated: frame 0
+        float *dst = AMP_OBS ? orow + 65 : o.dof_vel ? o.dof_vel + s * ND : nullptr;
+        if (dst)
+            for (int i = 14 * h; i < 14 * h + 14; ++i) dst[i] = t.dof_vel[f.r0 * ND + i];
+    }
+}
+
+// ------------------------------------------------------- amp obs on given arrays
+// full observation of one character; dof_pos / dof_vel read with a stride
+// (1 for separate arrays, 2 for the interleaved dof_state)
+__device__ __forceinline__ void amp_obs_full(f3 root_pos, f4 root_rot, f3 root_vel, f3 root_ang_vel,
+                                             const float *dof_pos, const float *dof_vel, int dstride,
+                                             const f3 (&key)[NK], bool local_root_obs, float *obs)
+{
+    f4 heading_rot;
+    float c[13];
+    root_obs(root_pos, root_rot, root_vel, root_ang_vel, local_root_obs, heading_rot, c);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) obs[i] = c[i];
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+        const int off = DOF_OFFSETS[j], size = DOF_OFFSETS[j + 1] - off;
+        float d[3] = {dof_pos[off * dstride], 0.0f, 0.0f}, o6[6];
+        if (size == 3) {
+            d[1] = dof_pos[(off + 1) * dstride];
+            d[2] = dof_pos[(off + 2) * dstride];
+        }
+        joint_obs(d, size, o6);
+        float *dst = obs + 13 + DOF_OBS_OFFSETS[j];
+        dst[0] = o6[0];
+        if (size == 3) { dst[1] = o6[1]; dst[2] = o6[2]; dst[3] = o6[3]; dst[4] = o6[4]; dst[5] = o6[5]; }
+    }
+#pragma unroll 4
+    for (int j = 0; j < ND; ++j) obs[65 + j] = dof_vel[j * dstride];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const f3 l = quat_rotate<false>(heading_rot, f3{key[k].x - root_pos.x, key[k].y - root_pos.y, key[k].z - root_pos.z});
+        obs[93 + 3 * k] = l.x; obs[94 + 3 * k] = l.y; obs[95 + 3 * k] = l.z;
+    }
+}
+
+__global__ __launch_bounds__(64) void amp_obs_kernel(const float *__restrict__ root_states, const float *__restrict__ dof_pos,
+                                                     const float *__restrict__ dof_vel, const float *__restrict__ key_pos,
+                                                     int local_root_obs, float *__restrict__ obs, int64_t n)
+{
+    __shared__ __align__(16) float s_tile[WAVE * NO];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
+    if (lane < nvalid) {
+        const int64_t e = base + lane;
+        const float *r = root_states + e * 13;
+        f3 key[NK];
+        for (int k = 0; k < NK; ++k) key[k] = load_v(key_pos + (e * NK + k) * 3);
+        amp_obs_full(load_v(r), load_q(r + 3), load_v(r + 7), load_v(r + 10), dof_pos + e * ND, dof_vel + e * ND, 1, key,
+                     local_root_obs != 0, s_tile + lane * NO);
+    }
+    wave_sync();
+    if (nvalid == WAVE && dev_aligned16(obs)) {
+        drain_rows<NO>(obs + base * NO, s_tile, nvalid, lane);
+    } else {
+        for (int i = lane; i < nvalid * NO; i += WAVE) obs[base * NO + i] = s_tile[i];
+    }
+}
+
+// ------------------------------------------------------------------ env step
+__device__ __forceinline__ bool is_contact_body(const igx_amp_params &p, int body)
+{
+    bool c = false;
+    for (int i = 0; i < p.num_contact_bodies; ++i) c |= p.contact_body_ids[i] == body;
+    return c;
+}
+
+// observation of environment e straight from the simulator tensors (reset path)
+__device__ __forceinline__ void env_obs_from_global(const igx_amp_params &p, const igx_amp_buffers &b, int64_t e, float *obs)
+{
+    const float *r = b.root_states + e * 13;
+    const float *ds = b.dof_state + e * (2 * ND);
+    f3 key[NK];
+    for (int k = 0; k < NK; ++k) key[k] = load_v(b.rigid_body_state + (e * NB + p.key_body_ids[k]) * 13);
+    amp_obs_full(load_v(r), load_q(r + 3), load_v(r + 7), load_v(r + 10), ds, ds + 1, 2, key, p.local_root_obs != 0, obs);
+}
+
+__global__ __launch_bounds__(WAVE) void amp_step_kernel(const igx_amp_params p, const igx_amp_buffers b, int64_t n)
+{
+    __shared__ __align__(16) float s_tile[WAVE * NO];       // new observation rows
+    __shared__ __align__(16) float s_in[WAVE * 2 * ND];     // dof_state slab, then the old newest AMP slots
+    __shared__ __align__(16) float s_root[WAVE * 13];
+    __shared__ unsigned s_contact[WAVE];
+    static_assert(WAVE * 2 * ND >= WAVE * 13, "slab");
+    const int lane = threadIdx.x;
+    const int K = p.num_amp_obs_steps;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
+    const bool full = nvalid == WAVE;
+    const bool live = lane < nvalid;
+    const int64_t e = base + lane;
+
+    // ---- loads: root rows and dof_state slab through LDS
+    int64_t prog = 0;
+    if (live) prog = ld_stream(b.progress + e);
+    v4f r_root[(WAVE * 13 / 4 + WAVE - 1) / WAVE], r_dof[WAVE * 2 * ND / 4 / WAVE];
+    if (full) {
+        load_chunks<WAVE * 13 / 4>(b.root_states + base * 13, r_root, lane);
+        load_chunks<WAVE * 2 * ND / 4>(b.dof_state + base * (2 * ND), r_dof, lane);
+    }
+    s_contact[lane] = 0;
+    park_rows<13>(r_root, b.root_states + base * 13, s_root, nvalid, lane);
+    park_rows<2 * ND>(r_dof, b.dof_state + base * (2 * ND), s_in, nvalid, lane);
+
+    // ---- contact forces: stream the tile's [64,15,3] slab through the fall-contact predicate
+    {
+        const float *cf = b.contact_forces + base * (NB * 3);
+        const int count = nvalid * NB * 3;
+        for (int i = lane; i < count; i += WAVE) {
+            const float v = ld_stream(cf + i);
+            const int env = i / (NB * 3), body = (i - env * NB * 3) / 3;
+            if (v > 0.1f && !is_contact_body(p, body)) atomicOr(&s_contact[env], 1u);
+        }
+    }
+    wave_sync();
+
+    // ---- per-env: observation, reset decision
+    if (live) {
+        const float *rr = s_root + lane * 13;
+        f3 key[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) key[k] = load_v(b.rigid_body_state + (e * NB + p.key_body_ids[k]) * 13);
+        bool fall_height = false;
+        for (int body = 0; body < NB; ++body) {
+            const float z = b.rigid_body_state[(e * NB + body) * 13 + 2];
+            fall_height |= (z < p.termination_height) && !is_contact_body(p, body);
+        }
+        amp_obs_full(load_v(rr), load_q(rr + 3), load_v(rr + 7), load_v(rr + 10), s_in + lane * 2 * ND,
+                     s_in + lane * 2 * ND + 1, 2, key, p.local_root_obs != 0, s_tile + lane * NO);
+        prog += 1;
+        int64_t terminated = 0;
+        if (p.enable_early_termination && s_contact[lane] != 0 && fall_height && prog > 1) terminated = 1;
+        st_stream(b.rew + e, 1.0f);
+        st_stream(b.reset + e, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
+        st_stream(b.terminate + e, terminated);
+        st_stream(b.progress + e, prog);
+    }
+    wave_sync();
+
+    // ---- observation rows out
+    if (full && dev_aligned16(b.obs)) {
+        drain_rows<NO>(b.obs + base * NO, s_tile, nvalid, lane);
+    } else {
+        for (int i = lane; i < nvalid * NO; i += WAVE) b.obs[base * NO + i] = s_tile[i];
+    }
+
+    // ---- AMP history: slot k+1 <- slot k (newest first), slot 0 <- new observation.
+    // Old slots are parked in LDS one slot at a time, oldest destination first.
+    float *amp = b.amp_obs + base * K * NO;
+    for (int k = K - 2; k >= 0; --k) {
+        // read slot k of every env of the tile, write it to slot k+1
+        for (int i = lane; i < nvalid * NO; i += WAVE) {
+            const int env = i / NO, c = i - env * NO;
+            const float v = amp[(env * K + k) * NO + c];
+            amp[(env * K + k + 1) * NO + c] = v;
+        }
+    }
+    for (int i = lane; i < nvalid * NO; i += WAVE) {
+        const int env = i / NO, c = i - env * NO;
+        amp[(env * K) * NO + c] = s_tile[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void amp_reset_kernel(const igx_amp_params p, const igx_amp_buffers b,
+                                                       const int64_t *__restrict__ env_ids, int64_t m,
+                                                       const igx_motion_state_out s)
+{
+    __shared__ float s_obs[64 * NO];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int K = p.num_amp_obs_steps;
+    if (i < m) {
+        const int64_t e = env_ids[i];
+        float *r = b.root_states + e * 13;
+        if (s.root_pos) for (int c = 0; c < 3; ++c) r[c] = s.root_pos[i * 3 + c];
+        if (s.root_rot) for (int c = 0; c < 4; ++c) r[3 + c] = s.root_rot[i * 4 + c];
+        if (s.root_vel) for (int c = 0; c < 3; ++c) r[7 + c] = s.root_vel[i * 3 + c];
+        if (s.root_ang_vel) for (int c = 0; c < 3; ++c) r[10 + c] = s.root_ang_vel[i * 3 + c];
+        float *ds = b.dof_state + e * (2 * ND);
+        for (int j = 0; j < ND; ++j) {
+            if (s.dof_pos) ds[2 * j] = s.dof_pos[i * ND + j];
+            if (s.dof_vel) ds[2 * j + 1] = s.dof_vel[i * ND + j];
+        }
+        b.progress[e] = 0;
+        b.reset[e] = 0;
+        b.terminate[e] = 0;
+        __threadfence_block();
+        float *obs = s_obs + lane * NO;
+        env_obs_from_global(p, b, e, obs);
+        for (int c = 0; c < NO; ++c) {
+            const float v = obs[c];
+            b.obs[e * NO + c] = v;
+            for (int k = 0; k < K; ++k) b.amp_obs[(e * K + k) * NO + c] = v;
+        }
+    }
+}
+
+static int check_tables(const igx_motion_tables *t, const char *who)
+{
+    if (!t) return fail(IGX_E_NULL, "%s: tables struct is NULL", who);
+    if (t->num_motions <= 0) return fail(IGX_E_PARAM, "%s: no motions loaded", who);
+    if (!t->motion_length || !t->motion_dt || !t->motion_num_frames || !t->frame_offset || !t->root_pos ||
+        !t->root_rot || !t->local_rot || !t->root_vel || !t->root_ang_vel || !t->key_pos || !t->dof_vel)
+        return fail(IGX_E_NULL, "%s: a motion table pointer is NULL", who);
+    return IGX_OK;
+}
+
+static int check_amp(const igx_amp_params *p, const igx_amp_buffers *b, int64_t n, const char *who)
+{
+    if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "%s: count %lld out of range", who, (long long)n);
+    if (p->num_amp_obs_steps < 2) return fail(IGX_E_PARAM, "%s: num_amp_obs_steps must be >= 2", who);
+    if (p->num_contact_bodies < 0 || p->num_contact_bodies > 4) return fail(IGX_E_PARAM, "%s: num_contact_bodies", who);
+    for (int k = 0; k < 4; ++k)
+        if (p->key_body_ids[k] < 0 || p->key_body_ids[k] >= NB) return fail(IGX_E_PARAM, "%s: key_body_ids[%d]", who, k);
+    if (n == 0) return IGX_OK;
+    if (!b->root_states || !b->dof_state || !b->rigid_body_state || !b->obs || !b->amp_obs || !b->reset ||
+        !b->terminate || !b->progress)
+        return fail(IGX_E_NULL, "%s: a required buffer is NULL", who);
+    if (!aligned16(b->root_states) || !aligned16(b->dof_state))
+        return fail(IGX_E_ALIGN, "%s: root_states / dof_state must be 16-byte aligned", who);
+    return IGX_OK;
+}
+
+}  // namespace igx
+
+using namespace igx;
+
+extern "C" int igx_motion_state(const igx_motion_tables *t, const int64_t *ids, const double *times, int64_t n,
+                                const igx_motion_state_out *out, igx_stream_t stream)
+{
+    int rc = check_tables(t, "igx_motion_state");
+    if (rc != IGX_OK) return rc;
+    if (n < 0 || n > ((int64_t)1 << 32)) return fail(IGX_E_SIZE, "igx_motion_state: n out of range");
+    if (n == 0) return IGX_OK;
+    if (!ids || !times || !out) return fail(IGX_E_NULL, "igx_motion_state: NULL argument");
+    const int64_t blocks = (n * 16 + 255) / 256;
+    hipLaunchKernelGGL((motion_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
+                       ids, times, n, *out, 0, nullptr, nullptr, (int64_t)0, (int64_t)0);
+    return launch_status("igx_motion_state");
+}
+
+extern "C" int igx_motion_amp_obs(const igx_motion_tables *t, const int64_t *ids, const double *times, int64_t n,
+                                  int32_t local_root_obs, float *out, const int64_t *out_rows, int64_t out_row_stride,
+                                  int64_t out_col_offset, igx_stream_t stream)
+{
+    int rc = check_tables(t, "igx_motion_amp_obs");
+    if (rc != IGX_OK) return rc;
+    if (n < 0 || n > ((int64_t)1 << 32)) return fail(IGX_E_SIZE, "igx_motion_amp_obs: n out of range");
+    if (n == 0) return IGX_OK;
+    if (!ids || !times || !out) return fail(IGX_E_NULL, "igx_motion_amp_obs: NULL argument");
+    if (out_row_stride < NO || out_col_offset < 0) return fail(IGX_E_PARAM, "igx_motion_amp_obs: bad output stride / offset");
+    igx_motion_state_out none = {};
+    const int64_t blocks = (n * 16 + 255) / 256;
+    hipLaunchKernelGGL((motion_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
+                       ids, times, n, none, (int)local_root_obs, out, out_rows, out_row_stride, out_col_offset);
+    return launch_status("igx_motion_amp_obs");
+}
+
+extern "C" int igx_amp_observations(const float *root_states, const float *dof_pos, const float *dof_vel,
+                                    const float *key_body_pos, int32_t local_root_obs, float *obs, int64_t n,
+                                    igx_stream_t stream)
+{
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "igx_amp_observations: n out of range");
+    if (n == 0) return IGX_OK;
+    if (!root_states || !dof_pos || !dof_vel || !key_body_pos || !obs) return fail(IGX_E_NULL, "igx_amp_observations: NULL argument");
+    hipLaunchKernelGGL(amp_obs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       root_states, dof_pos, dof_vel, key_body_pos, (int)local_root_obs, obs, n);
+    return launch_status("igx_amp_observations");
+}
+
+extern "C" int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int64_t n, igx_stream_t stream)
+{
+    int rc = check_amp(p, b, n, "igx_humanoid_amp_step");
+    if (rc != IGX_OK || n == 0) return rc;
+    if (!b->contact_forces || !b->rew) return fail(IGX_E_NULL, "igx_humanoid_amp_step: contact_forces / rew is NULL");
+    hipLaunchKernelGGL(amp_step_kernel, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0,
+                       static_cast<hipStream_t>(stream), *p, *b, n);
+    return launch_status("igx_humanoid_amp_step");
+}
+
+extern "C" int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, const int64_t *env_ids, int64_t m,
+                                      const igx_motion_state_out *state, igx_stream_t stream)
+{
+    int rc = check_amp(p, b, m, "igx_humanoid_amp_reset");
+    if (rc != IGX_OK || m == 0) return rc;
+    if (!env_ids || !state) return fail(IGX_E_NULL, "igx_humanoid_amp_reset: env_ids / state is NULL");
+    hipLaunchKernelGGL(amp_reset_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), *p,
+                       *b, env_ids, m, *state);
+    return launch_status("igx_humanoid_amp_reset");
+}

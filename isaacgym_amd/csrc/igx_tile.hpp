@@ -21,6 +21,8 @@ __device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontempora
 template <class T>
 __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
 
+__device__ __forceinline__ bool dev_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 // Compiler-level ordering point for the wave-synchronous LDS exchange.
 __device__ __forceinline__ void wave_sync()
 {

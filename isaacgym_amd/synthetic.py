@@ -191,3 +191,47 @@ def allegro_state(n, seed, device, obs_type="full_state", asymmetric=False):
         successes=torch.randint(0, 5, (n,), generator=gen, device=device).float(),
         consecutive_successes=torch.zeros(1, device=device),
         workspace=torch.zeros(16, device=device))
+
+
+# ---------------------------------------------------------------- HumanoidAMP
+def amp_params(num_amp_obs_steps=2, local_root_obs=False, enable_early_termination=True, max_episode_length=300):
+    return _abi.AmpParams(num_amp_obs_steps=num_amp_obs_steps, local_root_obs=int(local_root_obs),
+                          enable_early_termination=int(enable_early_termination), num_contact_bodies=2,
+                          contact_body_ids=[11, 14, 0, 0], key_body_ids=[5, 8, 11, 14], termination_height=0.5,
+                          max_episode_length_m1=float(max_episode_length - 1))
+
+
+def amp_state(n, seed, device, num_amp_obs_steps=2, max_episode_length=300):
+    """name->tensor dict of igx_amp_buffers; ~3 % of envs carry a contact force on a
+    non-foot body, about half of those also have a body below the termination height."""
+    NB, ND, NO = _abi.IGX_AMP_NUM_BODIES, _abi.IGX_AMP_NUM_DOF, _abi.IGX_AMP_OBS
+    gen = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=gen, device=device)  # noqa: E731
+    u = lambda *s: torch.rand(*s, generator=gen, device=device)  # noqa: E731
+    root = torch.empty(n, 13, device=device)
+    root[:, 0:3] = r(n, 3) * 0.5
+    root[:, 2] = 0.9 + r(n) * 0.1
+    root[:, 3:7] = _quats(n, gen, device)
+    root[:, 7:13] = r(n, 6)
+    dof_state = torch.empty(n, ND, 2, device=device)
+    dof_state[..., 0] = (u(n, ND) * 2 - 1) * 2.5
+    dof_state[..., 0] = torch.where(u(n, ND) < 0.02, torch.zeros((), device=device), dof_state[..., 0])
+    dof_state[..., 1] = r(n, ND) * 3.0
+    body = torch.empty(n, NB, 13, device=device)
+    body[..., 0:3] = root[:, None, 0:3] + r(n, NB, 3) * 0.3
+    body[..., 2] = 0.9 + r(n, NB) * 0.2
+    low = (u(n, NB) < 0.002)
+    body[..., 2] = torch.where(low, 0.3 + 0.1 * r(n, NB), body[..., 2])
+    body[..., 3:7] = _quats(n * NB, gen, device).view(n, NB, 4)
+    body[..., 7:13] = r(n, NB, 6)
+    cf = torch.zeros(n, NB, 3, device=device)
+    hit = (u(n, NB) < 0.004) | low & (u(n, NB) < 0.5)
+    cf = torch.where(hit.unsqueeze(-1), r(n, NB, 3) * 5.0, cf)
+    cf[:, [11, 14]] = r(n, 2, 3) * 50.0  # feet always in contact
+    return dict(
+        root_states=root, dof_state=dof_state, rigid_body_state=body, contact_forces=cf,
+        obs=torch.zeros(n, NO, device=device), amp_obs=r(n, num_amp_obs_steps, NO),
+        rew=torch.zeros(n, device=device),
+        reset=torch.zeros(n, dtype=torch.int64, device=device),
+        terminate=torch.zeros(n, dtype=torch.int64, device=device),
+        progress=torch.randint(0, max_episode_length + 1, (n,), generator=gen, device=device))

@@ -186,6 +186,23 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
 
+def assert_close_near_identity(x, ref, scale=1.0, rtol=RTOL, quantum=2e-2, max_frac=1e-4, what=""):
+    """assert_close for quantities derived from quat_to_angle_axis(slerp(...)) of a
+    nearly identity rotation.  fp32 slerp divides by sqrt(1 - c*c), which for close
+    frames is quantised to ~3e-5 relative, so its result is a unit quaternion only to
+    that precision; for an interpolated rotation within ~1e-2 rad of identity w can
+    land on exactly 1.0 (angle masked to zero, torch_jit_utils.py:423-444) or one ulp
+    below (angle*axis = 2*xyz) depending on the last bit of the math library's
+    acos / sin.  The reference has the same knife edge.  Such entries must be rare and
+    every difference outside rtol must stay below `quantum` rad."""
+    ok = close(x, ref, scale, rtol)
+    bad = ~ok
+    if bad.any():
+        d = np.abs(x[bad].astype(np.float64) - ref[bad])
+        assert bad.mean() <= max_frac, "%s: %d/%d outside tolerance" % (what, bad.sum(), bad.size)
+        assert (d < quantum).all(), "%s: max jump %g" % (what, d.max())
+
+
 def motion_tabs_from_golden(g):
     """igx_motion_tables (numpy) from the reference's per-frame tables in motion.npz."""
     M = len(g["motion_lengths"])
@@ -299,3 +316,22 @@ def amp_replay(g, fns, to_buf, to_np, zeros):
             # history = previous step's current slot, bit for bit
             assert np.array_equal(amp[:, 105:210], prev_curr), what + "amp_obs history"
         prev_curr = amp[:, :105].copy()
+
+
+def write_golden_motions(g, dirpath):
+    """Write motion.npz's raw motions as plain-array .npz motion files plus the
+    .yaml motion set naming them; returns the yaml path."""
+    import os
+    M = len(g["motion_lengths"])
+    lines = ["motions:"]
+    for i in range(M):
+        np.savez(os.path.join(dirpath, "m%d.npz" % i), rotation=g["m%d_rotation" % i],
+                 root_translation=g["m%d_root_translation" % i], global_velocity=g["m%d_global_velocity" % i],
+                 global_angular_velocity=g["m%d_global_angular_velocity" % i], parent_indices=g["parent_indices"],
+                 local_translation=g["local_translation"], fps=np.float64(g["motion_fps"][i]), is_local=np.bool_(True))
+        lines.append('  - file: "m%d.npz"' % i)
+        lines.append("    weight: %r" % float(g["meta"]["specs"][i][2]))
+    path = os.path.join(dirpath, "set.yaml")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return path

@@ -1,0 +1,187 @@
+"""GPU parity of the AMP motion library and the HumanoidAMP step / reset kernels:
+replay of the reference's golden recordings through the C ABI, and comparison
+with the CPU checker on larger seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from isaacgym_amd import ops, synthetic
+from isaacgym_amd.tasks.amp.utils_amp.motion_lib import MotionLib
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def motion():
+    g = H.load_golden("motion")
+    tabs_np = H.motion_tabs_from_golden(g)
+    tabs_dev = {k: dev(v) for k, v in tabs_np.items()}
+    return g, tabs_np, tabs_dev, ops.motion_tables(tabs_dev)
+
+
+def _state_out(n, frames=True):
+    f = dict(dtype=torch.float32, device=DEV)
+    out = dict(root_pos=torch.empty(n, 3, **f), root_rot=torch.empty(n, 4, **f), dof_pos=torch.empty(n, 28, **f),
+               root_vel=torch.empty(n, 3, **f), root_ang_vel=torch.empty(n, 3, **f), dof_vel=torch.empty(n, 28, **f),
+               key_pos=torch.empty(n, 4, 3, **f))
+    if frames:
+        out.update(frame_idx0=torch.empty(n, dtype=torch.int64, device=DEV),
+                   frame_idx1=torch.empty(n, dtype=torch.int64, device=DEV), blend=torch.empty(n, **f))
+    return out
+
+
+def test_motion_state_golden(motion):
+    g, _, _, tables = motion
+    out = _state_out(len(g["ids"]))
+    ops.motion_state(tables, dev(g["ids"]), dev(g["times"]), out)
+    H.check_motion_state({k: host(v) for k, v in out.items()}, g)
+
+
+def test_motion_state_partial_outputs(motion):
+    g, _, _, tables = motion
+    n = len(g["ids"])
+    out = dict(dof_pos=torch.empty(n, 28, device=DEV), frame_idx0=torch.empty(n, dtype=torch.int64, device=DEV))
+    ops.motion_state(tables, dev(g["ids"]), dev(g["times"]), out)
+    assert np.array_equal(host(out["frame_idx0"]), g["frame_idx0"])
+    H.assert_close(host(out["dof_pos"]), g["dof_pos"], scale=np.pi, what="dof_pos")
+
+
+@pytest.mark.parametrize("lro", [0, 1])
+def test_amp_observations_golden(motion, lro):
+    g = motion[0]
+    root = np.concatenate([g["root_pos"], g["root_rot"], g["root_vel"], g["root_ang_vel"]], axis=-1)
+    obs = torch.zeros(len(root), 105, device=DEV)
+    ops.amp_observations(dev(root), dev(g["dof_pos"]), dev(g["dof_vel"]), dev(g["key_pos"].reshape(-1, 12)), lro, obs)
+    H.assert_close(host(obs), g["amp_obs_local%d" % lro], what="amp obs")
+    want = oracle.amp_observations(root, g["dof_pos"], g["dof_vel"], g["key_pos"].reshape(-1, 12), lro)
+    H.assert_close(host(obs), want, what="amp obs vs checker")
+
+
+def test_fused_motion_amp_obs_golden(motion):
+    g, _, _, tables = motion
+    n = len(g["ids"])
+    ids, times = dev(g["ids"]), dev(g["times"])
+    out = torch.zeros(n, 105, device=DEV)
+    ops.motion_amp_obs(tables, ids, times, 0, out)
+    H.assert_close(host(out), g["amp_obs_local0"], what="fused amp obs")
+    buf = torch.zeros(n, 2, 105, device=DEV)
+    rows = np.random.default_rng(0).permutation(n).astype(np.int64)
+    ops.motion_amp_obs(tables, ids, times, 0, buf, out_rows=dev(rows), out_row_stride=210, out_col_offset=105)
+    b = host(buf)
+    assert np.array_equal(b[rows, 1], host(out))
+    assert not b[:, 0].any()
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 4097, 200000])
+def test_motion_state_vs_oracle(motion, n):
+    _, tabs_np, _, tables = motion
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, 2, n).astype(np.int64)
+    L = tabs_np["motion_length"][ids] if n else np.zeros(0)
+    times = rng.uniform(-0.2, 1.2, n) * L  # includes both out-of-range ends
+    out = _state_out(n)
+    ops.motion_state(tables, dev(ids), dev(times), out)
+    torch.cuda.synchronize()
+    if n == 0:
+        return
+    want = oracle.motion_state(tabs_np, ids, times)
+    got = {k: host(v) for k, v in out.items()}
+    for k in ("frame_idx0", "frame_idx1"):
+        assert np.array_equal(got[k], want[k]), k
+    for k in ("blend", "root_pos", "root_vel", "root_ang_vel", "dof_vel", "key_pos"):
+        assert H.bit_equal_fraction(got[k].reshape(want[k].shape), want[k]) == 1.0, k
+    H.assert_close(got["root_rot"], want["root_rot"], what="root_rot")
+    H.assert_close_near_identity(got["dof_pos"], want["dof_pos"], scale=np.pi, what="dof_pos")
+    fused = torch.zeros(n, 105, device=DEV)
+    ops.motion_amp_obs(tables, dev(ids), dev(times), 1, fused)
+    ref = np.zeros((n, 105), np.float32)
+    oracle.motion_amp_obs(tabs_np, ids, times, 1, ref)
+    H.assert_close_near_identity(host(fused), ref, scale=np.pi, rtol=2e-5, what="fused amp obs")
+
+
+def test_amp_task_golden(motion):
+    _, _, _, tables = motion
+    g = H.load_golden("amp")
+
+    def motion_state(ids, times):
+        out = _state_out(len(ids), frames=False)
+        del out["key_pos"]
+        ops.motion_state(tables, dev(ids), dev(times), out)
+        return out
+
+    fns = dict(step=ops.humanoid_amp_step,
+               reset=lambda p, b, env_ids, state: ops.humanoid_amp_reset(p, b, dev(env_ids), state),
+               motion_state=motion_state,
+               motion_amp_obs=lambda ids, times, lro, out, rows, stride, off:
+                   ops.motion_amp_obs(tables, dev(ids), dev(times), lro, out, dev(rows), stride, off))
+    H.amp_replay(g, fns, to_buf=dev, to_np=host,
+                 zeros=lambda shape, dt: torch.zeros(shape, device=DEV,
+                                                     dtype=torch.int64 if dt == np.int64 else torch.float32))
+
+
+@pytest.mark.parametrize("n,K,lro,early", [(0, 2, False, True), (1, 2, False, True), (67, 3, True, True),
+                                           (1000, 2, False, False), (100003, 4, True, True),
+                                           (1 << 18, 2, False, True)])
+def test_amp_step_vs_oracle(n, K, lro, early):
+    p = synthetic.amp_params(K, lro, early)
+    t = synthetic.amp_state(n, 5, DEV, K)
+    ref = {k: host(v).copy() for k, v in t.items()}
+    for step in range(2):
+        ops.humanoid_amp_step(p, t, n)
+        torch.cuda.synchronize()
+        if n == 0:
+            continue
+        oracle.humanoid_amp_step(p, ref, n)
+        for k in ("reset", "terminate", "progress"):
+            assert np.array_equal(host(t[k]), ref[k]), "%s step %d" % (k, step)
+        assert np.array_equal(host(t["rew"]), ref["rew"])
+        H.assert_close(host(t["obs"]), ref["obs"], scale=np.pi, rtol=2e-5, what="obs step %d" % step)
+        got, want = host(t["amp_obs"]), ref["amp_obs"]
+        H.assert_close(got[:, 0], want[:, 0], scale=np.pi, rtol=2e-5, what="amp_obs current")
+        if step == 0:  # shifted history is a copy: exact (later steps inherit slot 0's ulps)
+            assert np.array_equal(got[:, 1:].view(np.uint32), want[:, 1:].view(np.uint32))
+        else:
+            assert np.array_equal(got[:, 2:].view(np.uint32), want[:, 2:].view(np.uint32))
+        t["amp_obs"].copy_(torch.from_numpy(want))  # continue from identical histories
+    if n:
+        # reset of a scattered subset with given state rows
+        rng = np.random.default_rng(3)
+        env_ids = np.sort(rng.choice(n, size=max(1, n // 7), replace=False)).astype(np.int64)
+        m = len(env_ids)
+        st = synthetic.amp_state(m, 9, DEV, K)
+        state = dict(root_pos=st["root_states"][:, 0:3].contiguous(), root_rot=st["root_states"][:, 3:7].contiguous(),
+                     dof_pos=st["dof_state"][..., 0].contiguous(), root_vel=st["root_states"][:, 7:10].contiguous(),
+                     root_ang_vel=st["root_states"][:, 10:13].contiguous(), dof_vel=st["dof_state"][..., 1].contiguous())
+        ops.humanoid_amp_reset(p, t, dev(env_ids), state)
+        torch.cuda.synchronize()
+        oracle.humanoid_amp_reset(p, ref, env_ids, {k: host(v) for k, v in state.items()})
+        for k in ("reset", "terminate", "progress"):
+            assert np.array_equal(host(t[k]), ref[k]), "%s after reset" % k
+        for k in ("root_states", "dof_state"):
+            assert np.array_equal(host(t[k]).view(np.uint32), ref[k].view(np.uint32)), k
+        H.assert_close(host(t["obs"]), ref["obs"], scale=np.pi, rtol=2e-5, what="obs after reset")
+        H.assert_close(host(t["amp_obs"]), ref["amp_obs"], scale=np.pi, rtol=2e-5, what="amp_obs after reset")
+
+
+def test_product_motion_lib(motion, tmp_path):
+    g, tabs_np, _, _ = motion
+    ml = MotionLib(H.write_golden_motions(g, str(tmp_path)), 28, g["meta"]["key_body_ids"], DEV)
+    res = ml.get_motion_state(g["ids"], g["times"], return_frames=True)
+    names = ("root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "key_pos", "frame_idx0",
+             "frame_idx1", "blend")
+    H.check_motion_state({k: host(v) for k, v in zip(names, res)}, g)
+    assert len(ml.get_motion_state(g["ids"], g["times"])) == 7
+    H.assert_close(host(ml.get_amp_obs(g["ids"], g["times"], True)), g["amp_obs_local1"], what="get_amp_obs")
+    with pytest.raises(IndexError):
+        ml.get_motion_state(np.array([2]), np.array([0.0]))
