@@ -70,6 +70,12 @@ typedef struct igx_cartpole_buffers {
     int64_t *progress;   /* [N] in/out */
 } igx_cartpole_buffers;
 
+/* Cartpole.reset_idx (tasks/cartpole.py:148-162) for an explicit list of m
+ * environment ids: the same draws and arithmetic as the flagged resets inside
+ * igx_cartpole_step (rand, when given, is indexed by environment id). */
+int igx_cartpole_reset(const igx_cartpole_params *p, const igx_cartpole_buffers *b, const int64_t *env_ids,
+                       int64_t m, igx_stream_t stream);
+
 int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *b,
                       int64_t n_envs, igx_stream_t stream);
 
@@ -126,6 +132,17 @@ typedef struct igx_loco_buffers {
     int64_t *randomize;               /* [N] in/out, += 1; may be NULL */
     float *true_objective;            /* [N] out (Ant extras['true_objective']); may be NULL */
 } igx_loco_buffers;
+
+/* Ant.reset_idx (tasks/ant.py:339-366) / Humanoid.reset_idx (tasks/humanoid.py:360-390)
+ * for an explicit list of m environment ids: joints re-drawn around
+ * initial_dof_pos and clamped to the limits, potentials = prev_potentials from
+ * initial_root_states, progress = reset = 0.  Same draws as the flagged resets
+ * inside the step (rand, when given, is indexed by environment id); root_states
+ * is not touched, as in the reference. */
+int igx_ant_reset(const igx_loco_params *p, const igx_loco_buffers *b, const int64_t *env_ids, int64_t m,
+                  igx_stream_t stream);
+int igx_humanoid_reset(const igx_loco_params *p, const igx_loco_buffers *b, const int64_t *env_ids, int64_t m,
+                       igx_stream_t stream);
 
 int igx_ant_step(const igx_loco_params *p, const igx_loco_buffers *b,
                  int64_t n_envs, igx_stream_t stream);
@@ -300,6 +317,29 @@ int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int
  * igx_motion_amp_obs). */
 int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, const int64_t *env_ids, int64_t m,
                            const igx_motion_state_out *state, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * The part of VecTask.step every task shares (tasks/base/vec_task.py:401-418).
+ * ---------------------------------------------------------------------- */
+typedef struct igx_vec_task_tail {
+    const float *obs_buf;      /* [N,num_obs] */
+    float *obs_out;            /* clamp(obs_buf, -clip_obs, clip_obs) (:412); must not alias obs_buf */
+    int64_t obs_count;         /* N * num_obs floats */
+    const float *states_buf;   /* [N,num_states] or NULL */
+    float *states_out;         /* get_state() (:355, :415-416) */
+    int64_t states_count;      /* N * num_states floats, 0 without asymmetric observations */
+    const int64_t *progress;   /* [N] */
+    const int64_t *reset;      /* [N] */
+    uint8_t *time_outs;        /* [N] bool: (progress >= max_episode_length - 1) & (reset != 0) (:404); NULL skips */
+    double max_episode_length_m1;
+    float clip_obs;            /* env.clipObservations; +inf copies */
+    int32_t reserved;
+} igx_vec_task_tail;
+
+int igx_vec_task_tail_step(const igx_vec_task_tail *t, int64_t n_envs, igx_stream_t stream);
+
+/* torch.clamp(x, lo, hi) on count floats (the action clamp, tasks/base/vec_task.py:384); NaN stays NaN. */
+int igx_clamp(const float *x, float lo, float hi, float *out, int64_t count, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * torch_jit_utils math, one batched call per reference function

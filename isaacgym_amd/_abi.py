@@ -140,6 +140,13 @@ class AmpBuffers(_Struct):
                 ("progress", ptr)]
 
 
+class VecTaskTail(_Struct):
+    _fields_ = [("obs_buf", ptr), ("obs_out", ptr), ("obs_count", i64),
+                ("states_buf", ptr), ("states_out", ptr), ("states_count", i64),
+                ("progress", ptr), ("reset", ptr), ("time_outs", ptr),
+                ("max_episode_length_m1", C.c_double), ("clip_obs", f32), ("reserved", i32)]
+
+
 def make_buffers(cls, arrays, ptr_of):
     """Build a *Buffers struct from a name->array mapping.
 

@@ -18,15 +18,21 @@ _lib = None
 # every symbol include/igx.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _STEP_SIG = (C.c_int, [_P, _P, C.c_int64, _P])
+_RESET_SIG = (C.c_int, [_P, _P, _P, C.c_int64, _P])
 SYMBOLS = {
     "igx_version": (C.c_int, []),
     "igx_last_error_string": (C.c_char_p, []),
     "igx_cartpole_step": _STEP_SIG,
+    "igx_cartpole_reset": _RESET_SIG,
+    "igx_ant_reset": _RESET_SIG,
+    "igx_humanoid_reset": _RESET_SIG,
     "igx_ant_step": _STEP_SIG,
     "igx_humanoid_step": _STEP_SIG,
     "igx_allegro_pre_physics": _STEP_SIG,
     "igx_allegro_post_physics": _STEP_SIG,
 }
+SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
+SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])
 # AMP motion library / HumanoidAMP
 SYMBOLS.update({
     "igx_motion_state": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
@@ -136,6 +142,18 @@ def call_step(symbol, params, bufcls, tensors, n):
         raise ValueError("no device buffers given")
     with torch.cuda.device(dev):
         rc = getattr(lib(), symbol)(C.byref(params), C.byref(b), C.c_int64(n), current_stream(dev))
+    check(rc)
+
+
+def call_reset(symbol, params, bufcls, tensors, env_ids):
+    b, dev = make_buffers(bufcls, tensors)
+    if dev is None:
+        raise ValueError("no device buffers given")
+    if env_ids.device != dev:
+        raise ValueError("env_ids is on %s, buffers on %s" % (env_ids.device, dev))
+    with torch.cuda.device(dev):
+        rc = getattr(lib(), symbol)(C.byref(params), C.byref(b), tensor_ptr(env_ids, torch.int64),
+                                    C.c_int64(env_ids.shape[0]), current_stream(dev))
     check(rc)
 
 

@@ -49,7 +49,48 @@ __global__ __launch_bounds__(256) void cartpole_step_kernel(const igx_cartpole_p
     b.progress[e] = prog;
 }
 
+// reset_idx on an explicit id list: one lane per listed environment
+__global__ __launch_bounds__(256) void cartpole_reset_kernel(const igx_cartpole_params p, const igx_cartpole_buffers b,
+                                                             const int64_t *__restrict__ env_ids, int64_t m)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int64_t e = env_ids[i];
+    float u[4];
+    if (b.rand) {
+        const float4 r = reinterpret_cast<const float4 *>(b.rand)[e];
+        u[0] = r.x; u[1] = r.y; u[2] = r.z; u[3] = r.w;
+    } else {
+        philox_uniform4(p.seed, p.rng_offset, e, 0, u);
+    }
+    float4 ds;
+    ds.x = 0.9f * (u[0] - 0.5f);
+    ds.z = 0.9f * (u[1] - 0.5f);
+    ds.y = 0.5f * (u[2] - 0.5f);
+    ds.w = 0.5f * (u[3] - 0.5f);
+    reinterpret_cast<float4 *>(b.dof_state)[e] = ds;
+    b.reset[e] = 0;
+    b.progress[e] = 0;
+}
+
 }  // namespace igx
+
+extern "C" int igx_cartpole_reset(const igx_cartpole_params *p, const igx_cartpole_buffers *b, const int64_t *env_ids,
+                                  int64_t m, igx_stream_t stream)
+{
+    if (!p || !b) return igx::fail(IGX_E_NULL, "igx_cartpole_reset: params/buffers struct is NULL");
+    if (m < 0 || m > ((int64_t)1 << 38)) return igx::fail(IGX_E_SIZE, "igx_cartpole_reset: m %lld out of range", (long long)m);
+    if (m == 0) return IGX_OK;
+    IGX_REQUIRE_PTR(env_ids, "env_ids");
+    IGX_REQUIRE_PTR(b->dof_state, "dof_state");
+    IGX_REQUIRE_PTR(b->reset, "reset");
+    IGX_REQUIRE_PTR(b->progress, "progress");
+    IGX_REQUIRE_ALIGNED(b->dof_state, "dof_state");
+    if (b->rand) IGX_REQUIRE_ALIGNED(b->rand, "rand");
+    hipLaunchKernelGGL(igx::cartpole_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *p, *b, env_ids, m);
+    return igx::launch_status("igx_cartpole_reset");
+}
 
 extern "C" int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *b, int64_t n_envs,
                                  igx_stream_t stream)

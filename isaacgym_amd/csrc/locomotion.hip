@@ -316,6 +316,61 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
     }
 }
 
+// reset_idx on an explicit id list: lane (i, j) re-draws joint j of the i-th
+// listed environment; the j == 0 lane also writes the per-env scalars.
+template <int D>
+__global__ __launch_bounds__(256) void loco_reset_kernel(const igx_loco_params p, const igx_loco_buffers b,
+                                                         const int64_t *__restrict__ env_ids, int64_t m)
+{
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = gid / D;
+    const int j = (int)(gid - i * D);
+    if (i >= m) return;
+    const int64_t e = env_ids[i];
+    float up, uv;
+    if (b.rand) {
+        up = b.rand[e * (2 * D) + j];
+        uv = b.rand[e * (2 * D) + D + j];
+    } else {
+        float q[4];
+        philox_uniform4(p.seed, p.rng_offset, e, j >> 2, q);
+        const int a = j & 3;
+        up = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
+        philox_uniform4(p.seed, p.rng_offset, e, (D + j) >> 2, q);
+        const int c = (D + j) & 3;
+        uv = c == 0 ? q[0] : c == 1 ? q[1] : c == 2 ? q[2] : q[3];
+    }
+    const float dp = 0.4f * up + (-0.2f);
+    const float dv = 0.2f * uv + (-0.1f);
+    const float np_ = tensor_clamp(b.initial_dof_pos[e * D + j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);
+    reinterpret_cast<v2f *>(b.dof_state + e * (2 * D))[j] = v2f{np_, dv};
+    if (j == 0) {
+        const float *ir = b.initial_root_states + e * 13;
+        const float pot = -norm3(f3{p.targets[0] - ir[0], p.targets[1] - ir[1], 0.0f}) / p.dt;
+        b.potentials[e] = pot;
+        b.prev_potentials[e] = pot;
+        b.progress[e] = 0;
+        b.reset[e] = 0;
+    }
+}
+
+template <int D>
+static int launch_loco_reset(const igx_loco_params *p, const igx_loco_buffers *b, const int64_t *env_ids, int64_t m,
+                             igx_stream_t stream, const char *who)
+{
+    if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
+    if (m < 0 || m > ((int64_t)1 << 32)) return fail(IGX_E_SIZE, "%s: m %lld out of range", who, (long long)m);
+    if (p->num_dof != D) return fail(IGX_E_PARAM, "%s: expects num_dof=%d, got %d", who, D, p->num_dof);
+    if (m == 0) return IGX_OK;
+    if (!env_ids || !b->dof_state || !b->initial_dof_pos || !b->initial_root_states || !b->potentials ||
+        !b->prev_potentials || !b->progress || !b->reset)
+        return fail(IGX_E_NULL, "%s: a required pointer is NULL", who);
+    if (!aligned16(b->dof_state)) return fail(IGX_E_ALIGN, "%s: dof_state must be 16-byte aligned", who);
+    hipLaunchKernelGGL((loco_reset_kernel<D>), dim3((unsigned)((m * D + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *p, *b, env_ids, m);
+    return launch_status(who);
+}
+
 static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int D, int S, bool hum,
                       const char *who)
 {
@@ -371,4 +426,16 @@ extern "C" int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffer
     int rc = igx::check_loco(p, b, n_envs, 21, 12, true, "igx_humanoid_step");
     if (rc != IGX_OK) return rc;
     return igx::launch_loco<21, 12, true>(p, b, n_envs, stream, "igx_humanoid_step");
+}
+
+extern "C" int igx_ant_reset(const igx_loco_params *p, const igx_loco_buffers *b, const int64_t *env_ids, int64_t m,
+                             igx_stream_t stream)
+{
+    return igx::launch_loco_reset<8>(p, b, env_ids, m, stream, "igx_ant_reset");
+}
+
+extern "C" int igx_humanoid_reset(const igx_loco_params *p, const igx_loco_buffers *b, const int64_t *env_ids, int64_t m,
+                                  igx_stream_t stream)
+{
+    return igx::launch_loco_reset<21>(p, b, env_ids, m, stream, "igx_humanoid_reset");
 }

@@ -22,6 +22,18 @@ def humanoid_step(params, tensors, n_envs):
     _lib.call_step("igx_humanoid_step", params, _abi.LocoBuffers, tensors, n_envs)
 
 
+def cartpole_reset(params, tensors, env_ids):
+    _lib.call_reset("igx_cartpole_reset", params, _abi.CartpoleBuffers, tensors, env_ids)
+
+
+def ant_reset(params, tensors, env_ids):
+    _lib.call_reset("igx_ant_reset", params, _abi.LocoBuffers, tensors, env_ids)
+
+
+def humanoid_reset(params, tensors, env_ids):
+    _lib.call_reset("igx_humanoid_reset", params, _abi.LocoBuffers, tensors, env_ids)
+
+
 def allegro_pre_physics(params, tensors, n_envs):
     _lib.call_step("igx_allegro_pre_physics", params, _abi.AllegroBuffers, tensors, n_envs)
 
@@ -92,4 +104,42 @@ def humanoid_amp_reset(params, tensors, env_ids, state):
     with torch.cuda.device(dev):
         rc = _lib.lib().igx_humanoid_amp_reset(C.byref(params), C.byref(b), _lib.tensor_ptr(env_ids, torch.int64),
                                                C.c_int64(env_ids.shape[0]), C.byref(st), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
+# ---- VecTask.step tail --------------------------------------------------------
+def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_episode_length, states_buf=None,
+                  states_out=None):
+    """obs_out = clamp(obs_buf, +-clip_obs); states likewise; time_outs (torch.bool) =
+    (progress >= max_episode_length - 1) & (reset != 0)."""
+    f = torch.float32
+    dev = obs_buf.device
+    t = _abi.VecTaskTail()
+    t.obs_buf, t.obs_out, t.obs_count = _lib.tensor_ptr(obs_buf, f), _lib.tensor_ptr(obs_out, f), obs_buf.numel()
+    if obs_out.numel() != obs_buf.numel():
+        raise ValueError("obs_out must have as many elements as obs_buf")
+    if states_buf is not None and states_buf.numel():
+        if states_out is None or states_out.numel() != states_buf.numel():
+            raise ValueError("states_out must have as many elements as states_buf")
+        t.states_buf, t.states_out = _lib.tensor_ptr(states_buf, f), _lib.tensor_ptr(states_out, f)
+        t.states_count = states_buf.numel()
+    n = progress.shape[0]
+    if reset.shape[0] != n or time_outs.shape[0] != n:
+        raise ValueError("progress, reset and time_outs must have one entry per environment")
+    t.progress, t.reset = _lib.tensor_ptr(progress, torch.int64), _lib.tensor_ptr(reset, torch.int64)
+    t.time_outs = _lib.tensor_ptr(time_outs, torch.bool)
+    t.max_episode_length_m1 = float(max_episode_length - 1)
+    t.clip_obs = float(clip_obs)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_vec_task_tail_step(C.byref(t), C.c_int64(n), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
+def clamp(x, lo, hi, out):
+    dev = x.device
+    if out.numel() != x.numel():
+        raise ValueError("out must have as many elements as x")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_clamp(_lib.tensor_ptr(x, torch.float32), C.c_float(lo), C.c_float(hi),
+                                  _lib.tensor_ptr(out, torch.float32), C.c_int64(x.numel()), _lib.current_stream(dev))
     _lib.check(rc)

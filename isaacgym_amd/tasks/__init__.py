@@ -1,0 +1,30 @@
+"""Task classes with the reference's names (tasks/__init__.py: isaacgym_task_map)."""
+from .allegro_hand import AllegroHand
+from .ant import Ant
+from .cartpole import Cartpole
+from .humanoid import Humanoid
+from .humanoid_amp import HumanoidAMP
+
+isaacgym_task_map = {
+    "AllegroHand": AllegroHand,
+    "Ant": Ant,
+    "Cartpole": Cartpole,
+    "Humanoid": Humanoid,
+    "HumanoidAMP": HumanoidAMP,
+}
+
+
+def make(name, num_envs, device="cuda:0", seed=0, sim=None, **env_overrides):
+    """Task `name` with the default configuration on a SyntheticSim (or the given sim)."""
+    from ..cfg import task_config
+    from ..sim import SyntheticSim
+    cfg = task_config(name, num_envs, **env_overrides)
+    if sim is None:
+        extra = {}
+        if name == "AllegroHand":
+            extra["obs_type"] = cfg["env"]["observationType"]
+        if name == "HumanoidAMP":
+            extra["num_amp_obs_steps"] = cfg["env"]["numAMPObsSteps"]
+        sim = SyntheticSim(name, num_envs, device, seed=seed, **extra)
+    kw = {} if name == "HumanoidAMP" else dict(seed=seed)
+    return isaacgym_task_map[name](cfg, device, device, 0, True, False, False, sim=sim, **kw)

@@ -1,0 +1,50 @@
+"""Cartpole task: mirror of the reference's tasks/cartpole.py (class Cartpole)
+on the fused HIP step.  `post_physics_step` is one kernel (progress, flagged
+resets, observations, reward, reset flags; cartpole.py:170-178, :148-162,
+:135-146, :185-201); `reset_idx(env_ids)` is the same reset on an id list."""
+import torch
+
+from .. import _abi, ops
+from .base.vec_task import VecTask
+
+
+class Cartpole(VecTask):
+    def __init__(self, cfg, rl_device, sim_device, graphics_device_id=0, headless=True, virtual_screen_capture=False,
+                 force_render=False, sim=None, seed=0):
+        self.cfg = cfg
+        self.reset_dist = self.cfg["env"]["resetDist"]
+        self.max_push_effort = self.cfg["env"]["maxEffort"]
+        self.max_episode_length = 500
+        self.cfg["env"]["numObservations"] = 4
+        self.cfg["env"]["numActions"] = 1
+        super().__init__(self.cfg, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture,
+                         force_render, sim=sim)
+        self.num_dof = 2
+        self.dof_state = self.sim.acquire("dof_state")  # [N, 2, 2] interleaved (pos, vel)
+        view = self.dof_state.view(self.num_envs, self.num_dof, 2)
+        self.dof_pos = view[..., 0]
+        self.dof_vel = view[..., 1]
+        self.seed = int(seed)
+        self.reset_rand = None  # optional [N,4] pre-drawn uniforms replacing the in-kernel generator
+        self._draws = 0
+
+    def _params(self):
+        self._draws += 1
+        return _abi.CartpoleParams(reset_dist=self.reset_dist, max_episode_length_m1=float(self.max_episode_length - 1),
+                                   seed=self.seed, rng_offset=self._draws)
+
+    def _buffers(self):
+        return dict(dof_state=self.dof_state, rand=self.reset_rand, obs=self.obs_buf, rew=self.rew_buf,
+                    reset=self.reset_buf, progress=self.progress_buf)
+
+    def pre_physics_step(self, actions):  # cartpole.py:164-168
+        forces = torch.zeros(self.num_envs * self.num_dof, device=self.device, dtype=torch.float)
+        forces[::self.num_dof] = actions.to(self.device).squeeze() * self.max_push_effort
+        self.sim.apply_dof_forces(forces)
+
+    def post_physics_step(self):
+        ops.cartpole_step(self._params(), self._buffers(), self.num_envs)
+
+    def reset_idx(self, env_ids):
+        ops.cartpole_reset(self._params(), self._buffers(), env_ids.to(self.device, torch.int64).contiguous())
+        self.sim.notify_dof_state(env_ids)

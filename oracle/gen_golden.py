@@ -837,7 +837,83 @@ def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4):
           "terminated", int(out["terminate"].sum()), "resets", int(out["reset"].sum()))
 
 
-GENERATORS = {"motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+def gen_vectask(seed=21, N=301, T=3):
+    """VecTask.allocate_buffers / step tail / reset (tasks/base/vec_task.py:310-333,
+    :401-418, :436-449) of the reference's real base class, two configurations."""
+    vt = ref_shim.load_real_vec_task()
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    variants = {"clip5": dict(clip=5.0, num_obs=13, num_states=7, max_len=50),
+                "noclip": dict(clip=float("inf"), num_obs=60, num_states=0, max_len=1000)}
+    for name, v in variants.items():
+        frames = []
+
+        class Task(vt.VecTask):
+            def __init__(self):
+                pass
+
+            def pre_physics_step(self, actions):
+                self.actions = actions.clone()
+
+            def post_physics_step(self):
+                f = frames[self.control_steps]
+                self.obs_buf[:] = f["obs"]
+                if self.num_states:
+                    self.states_buf[:] = f["states"]
+                self.rew_buf[:] = f["rew"]
+                self.reset_buf[:] = f["reset"]
+                self.progress_buf[:] = f["progress"]
+
+        t = Task()
+        t.num_environments, t.num_observations, t.num_states, t.num_actions = N, v["num_obs"], v["num_states"], 3
+        t.device = t.rl_device = "cpu"
+        t.clip_obs, t.clip_actions = v["clip"], 1.0
+        t.dr_randomizations, t.control_freq_inv, t.force_render = {}, 1, False
+        t.gym, t.sim, t.control_steps, t.obs_dict = _Any(), None, 0, {}
+        t.max_episode_length = v["max_len"]
+        t.allocate_buffers()
+        for k in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf", "progress_buf", "randomize_buf"):
+            out["%s_alloc_%s" % (name, k)] = getattr(t, k).numpy().copy()
+        first = t.reset()
+        out[name + "_reset_obs"] = first["obs"].numpy().copy()
+        for step in range(T):
+            obs = torch.randn(N, v["num_obs"], generator=g) * 4.0
+            obs[0, 0], obs[1, 1], obs[2, 2] = float("nan"), float("inf"), float("-inf")
+            obs[3, 0], obs[4, 0] = 5.0, -5.0
+            progress = torch.randint(0, v["max_len"] + 2, (N,), generator=g)
+            progress[:4] = torch.tensor([v["max_len"] - 2, v["max_len"] - 1, v["max_len"], v["max_len"] - 1])
+            reset = (torch.rand(N, generator=g) < 0.5).long()
+            reset[:4] = torch.tensor([1, 1, 1, 0])
+            frames.append(dict(obs=obs, states=torch.randn(N, max(v["num_states"], 1), generator=g)[:, :v["num_states"]] * 6.0,
+                               rew=torch.randn(N, generator=g), reset=reset, progress=progress))
+        acts, outs = [], dict(obs=[], states=[], rew=[], reset=[], time_outs=[])
+        for step in range(T):
+            a = torch.randn(N, 3, generator=g) * 2.0
+            acts.append(a.numpy().copy())
+            obs_dict, rew, reset, extras = t.step(a)
+            outs["obs"].append(obs_dict["obs"].numpy().copy())
+            if v["num_states"]:
+                outs["states"].append(obs_dict["states"].numpy().copy())
+            outs["rew"].append(rew.numpy().copy())
+            outs["reset"].append(reset.numpy().copy())
+            outs["time_outs"].append(extras["time_outs"].numpy().copy())
+            out.setdefault(name + "_clipped_actions", []).append(t.actions.numpy().copy())
+        for k in ("obs", "states", "rew", "reset", "progress"):
+            if k == "states" and not v["num_states"]:
+                continue
+            out["%s_in_%s" % (name, k)] = np.stack([f[k].numpy() for f in frames])
+        out[name + "_in_actions"] = np.stack(acts)
+        out[name + "_clipped_actions"] = np.stack(out[name + "_clipped_actions"])
+        for k, lst in outs.items():
+            if lst:
+                out["%s_out_%s" % (name, k)] = np.stack(lst)
+    out["meta"] = _meta(task="VecTask", seed=seed, N=N, T=T,
+                        variants={k: dict(v, clip=(None if math.isinf(v["clip"]) else v["clip"])) for k, v in variants.items()})
+    np.savez_compressed(os.path.join(OUT, "vectask.npz"), **out)
+    print("vectask.npz", {k: (v.shape, v.dtype) for k, v in out.items() if hasattr(v, "shape")})
+
+
+GENERATORS = {"vectask": gen_vectask, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -264,6 +264,55 @@ int orc_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *
     return 0;
 }
 
+/* tasks/cartpole.py:148-162 on an explicit id list */
+int orc_cartpole_reset(const igx_cartpole_params *p, const igx_cartpole_buffers *b, const int64_t *env_ids, int64_t m)
+{
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t e = env_ids[i];
+        float *ds = b->dof_state + e * 4;
+        float u0 = draw(b->rand, e, 4, 0, p->seed, p->rng_offset);
+        float u1 = draw(b->rand, e, 4, 1, p->seed, p->rng_offset);
+        float u2 = draw(b->rand, e, 4, 2, p->seed, p->rng_offset);
+        float u3 = draw(b->rand, e, 4, 3, p->seed, p->rng_offset);
+        ds[0] = 0.9f * (u0 - 0.5f);
+        ds[2] = 0.9f * (u1 - 0.5f);
+        ds[1] = 0.5f * (u2 - 0.5f);
+        ds[3] = 0.5f * (u3 - 0.5f);
+        b->reset[e] = 0;
+        b->progress[e] = 0;
+    }
+    return 0;
+}
+
+/* tasks/ant.py:339-366 / tasks/humanoid.py:360-390 on an explicit id list */
+int orc_loco_reset(const igx_loco_params *p, const igx_loco_buffers *b, const int64_t *env_ids, int64_t m)
+{
+    const int D = p->num_dof;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t e = env_ids[i];
+        float *ds = b->dof_state + e * D * 2;
+        for (int j = 0; j < D; ++j) {
+            float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset);
+            float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset);
+            float pos = 0.4f * up + (-0.2f);
+            float vel = 0.2f * uv + (-0.1f);
+            float t = b->initial_dof_pos[e * D + j] + pos;
+            t = fminf(t, p->dof_limits_upper[j]);
+            t = fmaxf(t, p->dof_limits_lower[j]);
+            ds[2 * j] = t;
+            ds[2 * j + 1] = vel;
+        }
+        const float *ir = b->initial_root_states + e * 13;
+        float tt[3] = { p->targets[0] - ir[0], p->targets[1] - ir[1], 0.0f };
+        float pot = -norm3(tt) / p->dt;
+        b->potentials[e] = pot;
+        b->prev_potentials[e] = pot;
+        b->progress[e] = 0;
+        b->reset[e] = 0;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------- Ant and Humanoid --- */
 /* tasks/ant.py:376-386, :339-366, :463-497, :414-460, :332-337 and
  * tasks/humanoid.py:398-407, :360-390, :489-524, :434-486.

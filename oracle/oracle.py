@@ -69,6 +69,21 @@ def humanoid_step(params, bufs, n):
     _call(lib().orc_humanoid_step, params, _abi.LocoBuffers, bufs, n)
 
 
+def _reset(fn, params, bufcls, bufs, env_ids):
+    env_ids = np.ascontiguousarray(env_ids, np.int64)
+    b = _abi.make_buffers(bufcls, bufs, _np_ptr)
+    assert fn(C.byref(params), C.byref(b), C.c_void_p(env_ids.ctypes.data), C.c_int64(len(env_ids))) == 0
+
+
+def cartpole_reset(params, bufs, env_ids):
+    _reset(lib().orc_cartpole_reset, params, _abi.CartpoleBuffers, bufs, env_ids)
+
+
+def loco_reset(params, bufs, env_ids):
+    """Ant / Humanoid reset_idx on an explicit id list (num_dof taken from params)."""
+    _reset(lib().orc_loco_reset, params, _abi.LocoBuffers, bufs, env_ids)
+
+
 def allegro_pre_physics(params, bufs, n):
     _call(lib().orc_allegro_pre_physics, params, _abi.AllegroBuffers, bufs, n)
 
@@ -164,3 +179,11 @@ def affine(name, x, lower, upper):
     assert fn(C.c_void_p(x.ctypes.data), C.c_void_p(lower.ctypes.data), C.c_void_p(upper.ctypes.data),
               C.c_void_p(out.ctypes.data), C.c_int64(n), C.c_int32(d)) == 0
     return out
+
+
+# ---- VecTask.step tail (tasks/base/vec_task.py:404, :412): numpy restatement ----
+def vec_task_tail(obs_buf, clip_obs, progress, reset, max_episode_length):
+    """Returns (clamped obs, time_outs).  np.minimum / np.maximum propagate NaN like torch.clamp."""
+    clip = np.float32(clip_obs)
+    out = np.minimum(np.maximum(obs_buf, -clip), clip).astype(np.float32)
+    return out, (progress >= max_episode_length - 1) & (reset != 0)

@@ -66,6 +66,7 @@ def install():
     sys.modules["isaacgym"].gymutil = sys.modules["isaacgym.gymutil"]
     sys.modules["gym"].spaces = sys.modules["gym.spaces"]
     sys.modules["gym.spaces"].Box = _Any()
+    sys.modules["gym"].Space = object
 
     _ns("isaacgymenvs", IGE)
     _ns("isaacgymenvs.utils", os.path.join(IGE, "utils"))
@@ -79,6 +80,22 @@ def install():
 
     _stub("isaacgymenvs.tasks.base.vec_task", VecTask=VecTask)
     _installed = True
+
+
+def load_real_vec_task():
+    """The reference's own tasks/base/vec_task.py under a private module name (the
+    task modules keep importing the dummy VecTask registered above)."""
+    import importlib.util
+    install()
+    name = "_ref_vec_task_real"
+    if name not in sys.modules:
+        # annotations such as gymapi.SimParams are evaluated at class creation
+        sys.modules["isaacgym.gymapi"].__getattr__ = lambda k: object
+        spec = importlib.util.spec_from_file_location(name, os.path.join(IGE, "tasks", "base", "vec_task.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+    return sys.modules[name]
 
 
 def load(modname):

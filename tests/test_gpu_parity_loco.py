@@ -156,3 +156,33 @@ def test_rejects_bad_arguments():
         ops.ant_step(p, dict(t, obs=t["obs"].cpu()), 64)
     with pytest.raises(ValueError):
         ops.ant_step(p, dict(t, dof_state=t["dof_state"][..., 0]), 64)  # strided view
+
+
+@pytest.mark.parametrize("spec,reset", [(synthetic.ANT, ops.ant_reset), (synthetic.HUMANOID, ops.humanoid_reset)])
+@pytest.mark.parametrize("m_frac,with_rand", [(0.0, False), (0.01, True), (1.0, False)])
+def test_loco_reset_idx_vs_oracle(spec, reset, m_frac, with_rand):
+    n = 70001
+    p = synthetic.loco_params(spec, seed=42, rng_offset=17)
+    t = synthetic.loco_state(spec, n, 6, DEV, with_rand)
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    rng = np.random.default_rng(0)
+    ids = np.sort(rng.choice(n, size=int(n * m_frac), replace=False)).astype(np.int64)
+    reset(p, t, _to_dev(ids))
+    torch.cuda.synchronize()
+    oracle.loco_reset(p, ref, ids)
+    for k in ("dof_state", "potentials", "prev_potentials", "progress", "reset", "root_states", "obs"):
+        assert np.array_equal(t[k].cpu().numpy().view(np.uint8), ref[k].view(np.uint8)), k
+
+
+@pytest.mark.parametrize("with_rand", [False, True])
+def test_cartpole_reset_idx_vs_oracle(with_rand):
+    n = 4096
+    p = synthetic.cartpole_params(seed=3, rng_offset=4)
+    t = synthetic.cartpole_state(n, 2, DEV, with_rand)
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    ids = np.arange(0, n, 3).astype(np.int64)
+    ops.cartpole_reset(p, t, _to_dev(ids))
+    oracle.cartpole_reset(p, ref, ids)
+    for k in ("dof_state", "progress", "reset"):
+        assert np.array_equal(t[k].cpu().numpy().view(np.uint8), ref[k].view(np.uint8)), k
+    ops.cartpole_reset(p, t, _to_dev(np.zeros(0, np.int64)))  # empty list is a no-op

@@ -1,0 +1,299 @@
+"""The task classes (reference attribute names, VecTask.step API) on the GPU: replay of the
+reference recordings through `step`, and equivalence with the bare C-ABI calls."""
+import numpy as np
+import pytest
+import torch
+
+from isaacgym_amd import cfg as C
+from isaacgym_amd import ops, synthetic, tasks
+from isaacgym_amd.sim import ReplaySim, SyntheticSim, TensorSim
+from isaacgym_amd.tasks.amp.utils_amp.motion_lib import MotionLib
+from isaacgym_amd.tasks.base.vec_task import VecTask
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+# ------------------------------------------------------------------ VecTask base
+@pytest.mark.parametrize("variant", ["clip5", "noclip"])
+def test_vec_task_step_tail_golden(variant):
+    g = H.load_golden("vectask")
+    v = g["meta"]["variants"][variant]
+    N, T = g["meta"]["N"], g["meta"]["T"]
+
+    class Task(VecTask):
+        def pre_physics_step(self, actions):
+            self.actions = actions.clone()
+
+        def post_physics_step(self):
+            t = self.control_steps
+            self.obs_buf.copy_(dev(g[variant + "_in_obs"][t]))
+            if self.num_states:
+                self.states_buf.copy_(dev(g[variant + "_in_states"][t]))
+            self.rew_buf.copy_(dev(g[variant + "_in_rew"][t]))
+            self.reset_buf.copy_(dev(g[variant + "_in_reset"][t]))
+            self.progress_buf.copy_(dev(g[variant + "_in_progress"][t]))
+
+    env = dict(numEnvs=N, numObservations=v["num_obs"], numStates=v["num_states"], numActions=3, clipActions=1.0)
+    if v["clip"] is not None:
+        env["clipObservations"] = v["clip"]
+    task = Task(dict(env=env, sim=dict(dt=0.0166)), DEV, DEV, sim=TensorSim(N, DEV))
+    task.max_episode_length = v["max_len"]
+    for k in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "timeout_buf", "progress_buf", "randomize_buf"):
+        want = g["%s_alloc_%s" % (variant, k)]
+        got = host(getattr(task, k))
+        assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), k
+    assert np.array_equal(host(task.reset()["obs"]), g[variant + "_reset_obs"])
+    for t in range(T):
+        obs_dict, rew, reset, extras = task.step(dev(g[variant + "_in_actions"][t]))
+        assert np.array_equal(bits(host(obs_dict["obs"])), bits(g[variant + "_out_obs"][t]))
+        if v["num_states"]:
+            assert np.array_equal(bits(host(obs_dict["states"])), bits(g[variant + "_out_states"][t]))
+        assert extras["time_outs"].dtype == torch.bool
+        assert np.array_equal(host(extras["time_outs"]), g[variant + "_out_time_outs"][t])
+        assert np.array_equal(bits(host(rew)), bits(g[variant + "_out_rew"][t]))
+        assert np.array_equal(host(reset), g[variant + "_out_reset"][t])
+        assert np.array_equal(bits(host(task.actions)), bits(g[variant + "_clipped_actions"][t]))
+    assert task.control_steps == T
+
+
+@pytest.mark.parametrize("count", [0, 1, 3, 1023, 1024, 1025, 4099 * 60])
+def test_clamp_odd_sizes_and_alignment(count):
+    x = torch.randn(count + 1, device=DEV)[1:] * 3  # 4-byte aligned only
+    out = torch.full_like(x, 7.0)
+    ops.clamp(x.contiguous(), -1.5, 2.0, out)
+    assert torch.equal(out, torch.clamp(x, -1.5, 2.0))
+
+
+# -------------------------------------------------------------- Cartpole / Ant / Humanoid
+def test_cartpole_class_golden():
+    g = H.load_golden("cartpole")
+    m = g["meta"]
+    N, T = m["N"], m["T"]
+    frames = [dict(dof_state=g["in_dof_state"][t]) for t in range(T)]
+    sim = ReplaySim(N, DEV, dict(dof_state=g["in_dof_state"][0].reshape(N, 2, 2)), frames)
+    task = tasks.Cartpole(C.task_config("Cartpole", N), DEV, DEV, sim=sim)
+    assert task.reset_buf.all() and task.obs_buf.shape == (N, 4)
+    task.reset_buf.copy_(dev(g["reset0"]))
+    task.progress_buf.copy_(dev(g["progress0"]))
+    for t in range(T):
+        task.reset_rand = dev(g["rand"][t])
+        obs_dict, rew, reset, extras = task.step(torch.zeros(N, 1, device=DEV))
+        assert np.array_equal(host(task.reset_buf), g["reset"][t])
+        assert np.array_equal(host(task.progress_buf), g["progress"][t])
+        assert np.array_equal(bits(host(task.obs_buf)), bits(g["obs"][t]))
+        assert np.array_equal(bits(host(rew)), bits(g["rew"][t]))
+        assert np.array_equal(bits(host(task.dof_state).reshape(-1, 2)), bits(g["out_dof_state"][t]))
+        assert np.array_equal(host(obs_dict["obs"]), np.clip(g["obs"][t], -5.0, 5.0))
+        assert np.array_equal(host(extras["time_outs"]), (g["progress"][t] >= 499) & (g["reset"][t] != 0))
+        assert task.dof_pos.shape == (N, 2) and torch.equal(task.dof_pos[:, 1], task.obs_buf[:, 2])
+
+
+@pytest.mark.parametrize("name,cls,D,S", [("ant", tasks.Ant, 8, 24), ("humanoid", tasks.Humanoid, 21, 12)])
+def test_locomotion_class_golden(name, cls, D, S):
+    g = H.load_golden(name)
+    m = g["meta"]
+    N, T = m["N"], m["T"]
+    hum = name == "humanoid"
+
+    def frame(t):
+        f = dict(root_states=g["in_root"][t], dof_state=g["in_dof_state"][t], sensors=g["in_sensors"][t])
+        if hum:
+            f["dof_force"] = g["in_dof_force"][t]
+        return f
+
+    init = {k: np.asarray(v).reshape((N, D, 2) if k == "dof_state" else v.shape) for k, v in frame(0).items()}
+    asset = dict(dof_limits_lower=g["dof_limits_lower"].tolist(), dof_limits_upper=g["dof_limits_upper"].tolist())
+    if hum:
+        asset["motor_efforts"] = g["motor_efforts"].tolist()
+    sim = ReplaySim(N, DEV, init, [frame(t) for t in range(T)], asset)
+    task = cls(C.task_config(m["task"], N), DEV, DEV, sim=sim)
+    assert task.obs_buf.shape == (N, 60 if not hum else 108)
+    task.initial_root_states.copy_(dev(g["initial_root_states"]))
+    task.initial_dof_pos.copy_(dev(g["initial_dof_pos"]))
+    task.reset_buf.copy_(dev(g["reset0"]))
+    task.progress_buf.copy_(dev(g["progress0"]))
+    task.potentials.copy_(dev(g["potentials0"]))
+    nonangle = [c for c in range(task.num_obs) if c not in H.LOCO_ANGLE_COLS]
+    for t in range(T):
+        task.reset_rand = dev(g["rand"][t])
+        obs_dict, rew, reset, extras = task.step(dev(g["in_actions"][t]))
+        for k, ref in (("reset_buf", "reset"), ("progress_buf", "progress"), ("randomize_buf", "randomize")):
+            assert np.array_equal(host(getattr(task, k)), g[ref][t]), "%s step %d" % (k, t)
+        obs = host(task.obs_buf)
+        assert np.array_equal(bits(obs[:, nonangle]), bits(g["obs"][t][:, nonangle]))
+        H.assert_angle_close(obs[:, list(H.LOCO_ANGLE_COLS)], g["obs"][t][:, list(H.LOCO_ANGLE_COLS)], what="angles")
+        for k in ("potentials", "prev_potentials", "up_vec", "heading_vec"):
+            assert np.array_equal(bits(host(getattr(task, k))), bits(g[k][t])), k
+        assert np.array_equal(bits(host(rew)), bits(g["rew"][t]))
+        assert np.array_equal(bits(host(task.dof_state).reshape(-1, 2)), bits(g["out_dof_state"][t]))
+        assert np.array_equal(host(extras["time_outs"]), (g["progress"][t] >= 999) & (g["reset"][t] != 0))
+        if not hum:
+            assert np.array_equal(bits(host(extras["true_objective"])), bits(g["true_objective"][t]))
+        assert sim.tensors["dof_actuation_force"].shape == (N, D)
+
+
+def test_ant_reset_done_resets_everything_first():
+    task = tasks.make("Ant", 1000, DEV, seed=3)
+    obs_dict, ids = task.reset_done()  # reset_buf starts at ones
+    assert len(ids) == 1000 and not task.reset_buf.any() and not task.progress_buf.any()
+    lo, hi = task.dof_limits_lower, task.dof_limits_upper
+    assert bool(((task.dof_pos >= lo) & (task.dof_pos <= hi)).all())
+    assert bool((task.dof_vel.abs() <= 0.1).all())
+    assert torch.equal(task.potentials, task.prev_potentials)
+    _, ids = task.reset_done()
+    assert len(ids) == 0
+    for _ in range(3):
+        task.step(torch.rand(1000, 8, device=DEV) * 2 - 1)
+    assert task.control_steps == 3 and int(task.progress_buf.max()) == 3
+
+
+# ------------------------------------------------------------------------- AllegroHand
+@pytest.mark.parametrize("obs_type,asym", [("full_state", False), ("full", True), ("full_no_vel", False)])
+def test_allegro_class_equals_abi_calls(obs_type, asym):
+    n = 5000
+    task = tasks.make("AllegroHand", n, DEV, seed=4, observationType=obs_type, asymmetric_observations=asym)
+    assert task.obs_buf.shape == (n, {"full_state": 88, "full": 72, "full_no_vel": 50}[obs_type])
+    assert task.states_buf.shape == (n, 88 if asym else 0)
+    ref = synthetic.allegro_state(n, 4, DEV, obs_type, asym)  # what the sim drew
+    ref["reset"] = torch.ones(n, dtype=torch.int64, device=DEV)
+    ref["reset_goal"] = torch.ones(n, dtype=torch.int64, device=DEV)
+    ref["progress"].zero_()
+    ref["successes"].zero_()
+    orig = synthetic.allegro_state(n, 4, DEV, obs_type)
+    for step in range(3):
+        act = torch.rand(n, 16, device=DEV) * 2 - 1
+        obs_dict, rew, reset, extras = task.step(act)
+        p = synthetic.allegro_params(obs_type, seed=4, rng_offset=2 * step + 1,
+                                     dof_speed_scale_dt=20.0 * task.dt)
+        ref["actions"] = act.clone()
+        ops.allegro_pre_physics(p, ref, n)
+        for k in ("dof_state", "dof_force", "root_state_tensor"):
+            ref[k].copy_(orig[k])  # controlFrequencyInv = 2 simulate() calls land on the sim's first state set
+        p.rng_offset = 2 * step + 2
+        ops.allegro_post_physics(p, ref, n)
+        for k, a in (("obs", task.obs_buf), ("rew", task.rew_buf), ("reset", task.reset_buf),
+                     ("reset_goal", task.reset_goal_buf), ("progress", task.progress_buf),
+                     ("successes", task.successes), ("consecutive_successes", task.consecutive_successes),
+                     ("cur_targets", task.cur_targets), ("goal_states", task.goal_states)):
+            assert torch.equal(a, ref[k]), "%s step %d" % (k, step)
+        if asym:
+            assert torch.equal(task.states_buf, ref["states"])
+            assert torch.equal(obs_dict["states"], torch.clamp(ref["states"], -5.0, 5.0))
+        assert torch.equal(obs_dict["obs"], torch.clamp(ref["obs"], -5.0, 5.0))
+        assert float(extras["consecutive_successes"]) == float(ref["consecutive_successes"])
+
+
+# ------------------------------------------------------------------------- HumanoidAMP
+@pytest.fixture(scope="module")
+def motion_lib(tmp_path_factory):
+    g = H.load_golden("motion")
+    path = H.write_golden_motions(g, str(tmp_path_factory.mktemp("motions")))
+    return MotionLib(path, 28, [5, 8, 11, 14], DEV)
+
+
+def _amp_task(motion_lib, n, **over):
+    cfg = C.task_config("HumanoidAMP", n, **over)
+    sim = SyntheticSim("HumanoidAMP", n, DEV, seed=7, num_amp_obs_steps=cfg["env"]["numAMPObsSteps"])
+    return tasks.HumanoidAMP(cfg, DEV, DEV, sim=sim, motion_lib=motion_lib)
+
+
+def test_amp_class_reset_draws_the_reference_samples(motion_lib):
+    """np.random.seed(777) + reset_idx(env_ids): the reference drew reset_motion_ids / times
+    (tests/golden/amp.npz); same generator, same call order -> same draws."""
+    g = H.load_golden("amp")
+    m = g["meta"]
+    N = m["N"]
+    frames = [dict(root_states=g["in_root"][t], dof_state=g["in_dof_state"][t],
+                   rigid_body_state=g["in_rigid_body_state"][t], contact_forces=g["in_contact_forces"][t])
+              for t in range(m["T"])]
+    init = dict(root_states=g["in_root"][0], dof_state=g["in_dof_state"][0].reshape(N, 28, 2),
+                rigid_body_state=g["in_rigid_body_state"][0].reshape(N, 15, 13),
+                contact_forces=g["in_contact_forces"][0])
+    sim = ReplaySim(N, DEV, init, frames)
+    cfg = C.task_config("HumanoidAMP", N, controlFrequencyInv=1)
+    cfg["sim"]["dt"] = m["dt"]
+    task = tasks.HumanoidAMP(cfg, DEV, DEV, sim=sim, motion_lib=motion_lib)
+    assert task.dt == m["dt"] and task.get_num_amp_obs() == 210
+    task.reset_buf.zero_()
+    for t in range(2):
+        if t == 1:
+            task.progress_buf[:4] = torch.tensor([296, 297, 298, 299], device=DEV)
+        _, rew, reset, extras = task.step(torch.zeros(N, 28, device=DEV))
+        for k, a in (("reset", task.reset_buf), ("terminate", extras["terminate"]), ("progress", task.progress_buf)):
+            assert np.array_equal(host(a), g[k][t]), "%s step %d" % (k, t)
+        H.assert_close(host(task.obs_buf), g["obs"][t], what="obs")
+        H.assert_close(host(extras["amp_obs"])[:, :105], g["amp_obs"][t][:, :105], what="amp_obs")
+    np.random.seed(m["np_seed"])
+    obs_dict, ids = task.reset_done()
+    assert np.array_equal(host(ids), g["reset_env_ids"])
+    assert np.array_equal(task._reset_ref_motion_ids, g["reset_motion_ids"])
+    assert np.array_equal(task._reset_ref_motion_times, g["reset_motion_times"])
+    for k, a in (("progress", task.progress_buf), ("reset", task.reset_buf), ("terminate", task._terminate_buf)):
+        assert np.array_equal(host(a), g["reset_after_" + k]), k
+    H.assert_close(host(task._root_states), g["reset_after_root"], what="root")
+    H.assert_close(host(task._dof_state).reshape(-1, 2), g["reset_after_dof_state"], scale=np.pi, what="dof")
+    mask = np.zeros(N, bool)
+    mask[g["reset_env_ids"]] = True
+    H.assert_close(host(task.obs_buf)[mask], g["reset_after_obs"][mask], scale=np.pi, rtol=2e-5, what="obs")
+    H.assert_close(host(task._amp_obs_buf)[mask], g["reset_after_amp_obs"][mask], scale=np.pi, rtol=2e-5,
+                   what="amp_obs")
+
+
+def test_amp_fetch_demo_matches_unfused_path(motion_lib):
+    task = _amp_task(motion_lib, 256, numAMPObsSteps=3)
+    np.random.seed(5)
+    demo = task.fetch_amp_obs_demo(64)
+    assert demo.shape == (64, 3 * 105)
+    np.random.seed(5)
+    ids = motion_lib.sample_motions(64)
+    t0 = motion_lib.sample_time(ids)
+    ids3 = np.tile(ids[:, None], [1, 3]).flatten()
+    t3 = (t0[:, None] + (-task.dt * np.arange(3))).flatten()
+    rp, rr, dp, rv, rav, dv, kp = motion_lib.get_motion_state(ids3, t3)
+    want = torch.zeros(64 * 3, 105, device=DEV)
+    ops.amp_observations(torch.cat([rp, rr, rv, rav], dim=-1).contiguous(), dp, dv, kp.reshape(-1, 12).contiguous(),
+                         False, want)
+    assert torch.equal(demo, want.view(64, 315))
+    np.random.seed(6)
+    assert task.fetch_amp_obs_demo(64).data_ptr() == demo.data_ptr()  # buffer is reused
+
+
+@pytest.mark.parametrize("state_init", ["Default", "Start", "Hybrid"])
+def test_amp_state_init_modes(motion_lib, state_init):
+    n = 512
+    task = _amp_task(motion_lib, n, stateInit=state_init)
+    np.random.seed(1)
+    torch.manual_seed(1)
+    root_before = task._root_states.clone()
+    _, ids = task.reset_done()
+    assert len(ids) == n and not task.reset_buf.any() and not task._terminate_buf.any()
+    if state_init == "Default":
+        assert torch.equal(task._root_states, root_before)
+        assert torch.equal(task._dof_pos, task._initial_dof_pos) and not task._dof_vel.any()
+        assert torch.equal(task._amp_obs_buf[:, 1], task._amp_obs_buf[:, 0])
+    elif state_init == "Start":
+        assert not np.any(task._reset_ref_motion_times)
+        rp = motion_lib.get_motion_state(task._reset_ref_motion_ids, task._reset_ref_motion_times)[0]
+        assert torch.equal(task._root_states[:, 0:3], rp)
+    else:
+        n_ref, n_def = len(task._reset_ref_env_ids), len(task._reset_default_env_ids)
+        assert n_ref + n_def == n and 150 < n_ref < 362
+        d = task._reset_default_env_ids
+        assert torch.equal(task._dof_pos[d], task._initial_dof_pos[d])
+    assert torch.equal(task.obs_buf, task._amp_obs_buf[:, 0])
+    task.step(torch.zeros(n, 28, device=DEV))
+    assert int(task.progress_buf.min()) == 1
