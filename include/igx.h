@@ -217,6 +217,19 @@ int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffe
 int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
                              int64_t n_envs, igx_stream_t stream);
 
+/* Environment-sharded form of igx_allegro_post_physics (one shard per GPU).
+ * compute_hand_reward's consecutive_successes (tasks/allegro_hand.py:714-719)
+ * averages over ALL environments, so a shard stops after leaving its 16-byte
+ * record {uint64 num_resets; double sum(successes * resets)} at b->workspace;
+ * the caller gathers the records of all shards (rank order) and every rank
+ * calls igx_allegro_finalize_shards, which adds them in index order, updates
+ * consecutive_successes[0] and re-zeroes b->workspace. */
+#define IGX_ALLEGRO_SHARD_RECORD_BYTES 16
+int igx_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n_envs,
+                                   igx_stream_t stream);
+int igx_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
+                                int32_t num_shards, igx_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * HumanoidAMP and the AMP motion library.  The character is the reference's
  * 15-body / 28-dof AMP humanoid: DOF_BODY_IDS, DOF_OFFSETS and the four key

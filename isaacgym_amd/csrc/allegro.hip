@@ -366,12 +366,20 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         drain_rows<NOBS>(b.states + base * NOBS, s_tile, nvalid, lane);
 }
 
-// :714-719 consecutive_successes update from the two global sums
-__global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_allegro_buffers b)
+// :714-719 consecutive_successes update from the two global sums: the records of
+// all shards (this device's own workspace when there is one shard) are added in
+// index order, so every rank of a sharded run computes the same bits
+__global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
+                                        const AllegroWorkspace *__restrict__ records, int num_records)
 {
     AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
-    const unsigned long long num_resets = ws->num_resets;
-    const float fin = (float)ws->finished;
+    unsigned long long num_resets = 0;
+    double finished = 0.0;
+    for (int i = 0; i < num_records; ++i) {
+        num_resets += records[i].num_resets;
+        finished += records[i].finished;
+    }
+    const float fin = (float)finished;
     if (num_resets > 0) {
         const float cons = b.consecutive_successes[0];
         b.consecutive_successes[0] = p.av_factor * fin / (float)(long long)num_resets + p.one_minus_av_factor * cons;
@@ -435,11 +443,11 @@ extern "C" int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_al
     return launch_status("igx_allegro_pre_physics");
 }
 
-extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
-                                        igx_stream_t stream)
+// observation / reward launches; leaves this shard's {num_resets, sum(successes * resets)}
+// record in b->workspace
+static int allegro_post_launch(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, igx_stream_t stream)
 {
-    int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics");
-    if (rc != IGX_OK || n == 0) return rc;
+    int rc;
     const unsigned tiles = (unsigned)((n + WAVE - 1) / WAVE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->obs_type) {
@@ -464,6 +472,39 @@ extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_a
         rc = launch_status("igx_allegro_post_physics(states)");
         if (rc != IGX_OK) return rc;
     }
-    hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, s, *p, *b);
+    return IGX_OK;
+}
+
+extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
+                                        igx_stream_t stream)
+{
+    int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics");
+    if (rc != IGX_OK || n == 0) return rc;
+    rc = allegro_post_launch(p, b, n, stream);
+    if (rc != IGX_OK) return rc;
+    hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), *p, *b,
+                       reinterpret_cast<const AllegroWorkspace *>(b->workspace), 1);
     return launch_status("igx_allegro_post_physics(finalize)");
+}
+
+extern "C" int igx_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
+                                              igx_stream_t stream)
+{
+    int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics_shard");
+    if (rc != IGX_OK || n == 0) return rc;
+    return allegro_post_launch(p, b, n, stream);
+}
+
+extern "C" int igx_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
+                                           int32_t num_shards, igx_stream_t stream)
+{
+    if (!p || !b) return fail(IGX_E_NULL, "igx_allegro_finalize_shards: params/buffers struct is NULL");
+    if (num_shards < 1 || num_shards > 65536) return fail(IGX_E_SIZE, "igx_allegro_finalize_shards: num_shards %d", num_shards);
+    if (!records || !b->consecutive_successes || !b->workspace)
+        return fail(IGX_E_NULL, "igx_allegro_finalize_shards: records / consecutive_successes / workspace is NULL");
+    if (!aligned16(records) || !aligned16(b->workspace))
+        return fail(IGX_E_ALIGN, "igx_allegro_finalize_shards: records and workspace must be 16-byte aligned");
+    hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), *p, *b,
+                       static_cast<const AllegroWorkspace *>(records), (int)num_shards);
+    return launch_status("igx_allegro_finalize_shards");
 }

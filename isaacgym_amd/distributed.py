@@ -1,0 +1,93 @@
+"""Multi-GPU layout of the step path: one process per GPU, environments sharded.
+
+Every function on the path is per-environment, so a job of N environments on G
+GPUs gives rank r the contiguous block `env_shard(N, r, G)` of every buffer and
+the step itself moves no data between GPUs.  The only exchanges are tiny and
+sit beside the path:
+
+* AllegroHand's `consecutive_successes` averages over all environments
+  (tasks/allegro_hand.py:714-719 of the reference): each shard leaves a 16-byte
+  record, `gather_records` all-gathers them (RCCL over xGMI, one 16 x G byte
+  collective) and every rank adds them in rank order, so all ranks hold the
+  same value bit for bit;
+* imitation batches (`fetch_amp_obs_demo`) are sampled per rank and
+  `all_gather_rows` concatenates them when a global batch is wanted.
+
+`torch.distributed` is used as shipped: backend "nccl" (= RCCL on ROCm) for
+device tensors, "gloo" for host tensors (tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_shard(num_envs, rank, world_size):
+    """(start, count) of rank's contiguous block; the first num_envs % world_size ranks get one more."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, extra = divmod(int(num_envs), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def shard_seed(seed, rank):
+    """Per-rank generator key: the in-kernel Philox counter is the *local* environment index,
+    so shards must not share a key."""
+    return (int(seed) ^ (int(rank) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    (torch.distributed.run sets them).  Returns (rank, local_rank, world_size); a single
+    process without those variables is a world of one and initialises nothing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def gather_records(record, group=None):
+    """All-gather one fixed-size record per rank: 1-D tensor [R] -> [world, R], rank order."""
+    record = record.contiguous()
+    w = world_size(group)
+    if w == 1:
+        return record.unsqueeze(0).clone()
+    flat = record.reshape(-1)
+    out = torch.empty(w * flat.numel(), dtype=record.dtype, device=record.device)
+    dist.all_gather_into_tensor(out, flat, group=group)  # concatenation along dim 0, rank order
+    return out.view((w,) + tuple(record.shape))
+
+
+def all_gather_rows(rows, group=None):
+    """Concatenate equally sized per-rank batches [n, ...] -> [world * n, ...], rank order."""
+    rows = rows.contiguous()
+    w = world_size(group)
+    if w == 1:
+        return rows
+    out = torch.empty((w * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, rows, group=group)
+    return out
+
+
+def max_over_ranks(value, device, group=None):
+    """MAX of a host scalar over the ranks (benchmark timing)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

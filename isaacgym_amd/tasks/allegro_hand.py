@@ -14,7 +14,7 @@ kernel applies them.
 import numpy as np
 import torch
 
-from .. import _abi, ops
+from .. import _abi, distributed, ops
 from .base.vec_task import VecTask
 
 
@@ -44,8 +44,12 @@ def success_threshold_c(tolerance):
 
 class AllegroHand(VecTask):
     def __init__(self, cfg, rl_device, sim_device, graphics_device_id=0, headless=True, virtual_screen_capture=False,
-                 force_render=False, sim=None, seed=0):
+                 force_render=False, sim=None, seed=0, process_group=None):
+        """With torch.distributed initialised (one process per GPU, each owning a shard of
+        the environments) consecutive_successes is averaged over all shards, as the
+        reference averages over all environments."""
         self.cfg = cfg
+        self._group = process_group
         env = cfg["env"]
         self.dist_reward_scale = env["distRewardScale"]
         self.rot_reward_scale = env["rotRewardScale"]
@@ -170,7 +174,13 @@ class AllegroHand(VecTask):
         self.sim.apply_dof_position_targets(self.cur_targets)
 
     def post_physics_step(self):
-        ops.allegro_post_physics(self._params(), self._buffers(), self.num_envs)
+        if distributed.world_size(self._group) > 1:
+            p, b = self._params(), self._buffers()
+            ops.allegro_post_physics_shard(p, b, self.num_envs)
+            records = distributed.gather_records(self._workspace.view(torch.uint8)[:16], self._group)
+            ops.allegro_finalize_shards(p, b, records)
+        else:
+            ops.allegro_post_physics(self._params(), self._buffers(), self.num_envs)
         self.extras["consecutive_successes"] = self.consecutive_successes.mean()
         if self.print_success_stat:  # :395-404 (host prints: synchronises, as in the reference)
             self.total_resets = self.total_resets + self.reset_buf.sum()

@@ -752,7 +752,9 @@ static void allegro_obs_row(const igx_allegro_params *p, const igx_allegro_buffe
 
 /* tasks/allegro_hand.py:627-632 post_physics_step, :406-504 observations,
  * :663-719 compute_hand_reward */
-int orc_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n)
+typedef struct { uint64_t num_resets; double finished; } allegro_record;
+
+static int allegro_post(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, allegro_record *rec)
 {
     const int D = IGX_ALLEGRO_DOF;
     const int nobs = p->obs_type == IGX_ALLEGRO_OBS_FULL_STATE ? 88 : p->obs_type == IGX_ALLEGRO_OBS_FULL ? 72 : 50;
@@ -807,11 +809,46 @@ int orc_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buff
         num_resets += resets;
         fin += (double)(successes * (float)resets);
     }
+    rec->num_resets = (uint64_t)num_resets;
+    rec->finished = fin;
+    return 0;
+}
+
+static void allegro_finalize(const igx_allegro_params *p, const igx_allegro_buffers *b, const allegro_record *recs,
+                             int count)
+{
+    uint64_t num_resets = 0;
+    double fin = 0.0;
+    for (int i = 0; i < count; ++i) {
+        num_resets += recs[i].num_resets;
+        fin += recs[i].finished;
+    }
     if (num_resets > 0) {
         float f = (float)fin;
         b->consecutive_successes[0] =
-            p->av_factor * f / (float)num_resets + p->one_minus_av_factor * b->consecutive_successes[0];
+            p->av_factor * f / (float)(int64_t)num_resets + p->one_minus_av_factor * b->consecutive_successes[0];
     }
+}
+
+int orc_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n)
+{
+    allegro_record rec;
+    allegro_post(p, b, n, &rec);
+    allegro_finalize(p, b, &rec, 1);
+    return 0;
+}
+
+/* one shard of an environment-sharded run: the record goes to b->workspace */
+int orc_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n)
+{
+    return allegro_post(p, b, n, (allegro_record *)b->workspace);
+}
+
+int orc_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
+                                int32_t num_shards)
+{
+    allegro_finalize(p, b, (const allegro_record *)records, num_shards);
+    memset(b->workspace, 0, sizeof(allegro_record));
     return 0;
 }
 

@@ -92,6 +92,18 @@ def allegro_post_physics(params, bufs, n):
     _call(lib().orc_allegro_post_physics, params, _abi.AllegroBuffers, bufs, n)
 
 
+def allegro_post_physics_shard(params, bufs, n):
+    _call(lib().orc_allegro_post_physics_shard, params, _abi.AllegroBuffers, bufs, n)
+
+
+def allegro_finalize_shards(params, bufs, records):
+    """records: uint8 array [num_shards, 16] gathered in rank order."""
+    records = np.ascontiguousarray(records, np.uint8)
+    b = _abi.make_buffers(_abi.AllegroBuffers, bufs, _np_ptr)
+    assert lib().orc_allegro_finalize_shards(C.byref(params), C.byref(b), C.c_void_p(records.ctypes.data),
+                                             C.c_int32(records.shape[0])) == 0
+
+
 # ---- AMP motion library / observations ------------------------------------
 def motion_tables(tabs):
     """tabs: dict of numpy arrays named like igx_motion_tables fields."""

@@ -1,0 +1,112 @@
+"""The N > 1 layout on CPU: two gloo ranks, environments sharded, the product's
+collective helpers, the CPU checker standing in for the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from isaacgym_amd import distributed, synthetic
+from oracle import oracle
+
+
+def test_env_shard_partitions_exactly():
+    for n in (0, 1, 7, 64, 1 << 20, (1 << 20) + 5):
+        for w in (1, 2, 3, 8):
+            blocks = [distributed.env_shard(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n
+            for (s0, c0), (s1, _) in zip(blocks, blocks[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+    with pytest.raises(ValueError):
+        distributed.env_shard(10, 2, 2)
+    assert len({distributed.shard_seed(5, r) for r in range(8)}) == 8 and distributed.shard_seed(5, 0) == 5
+
+
+def test_single_process_is_a_world_of_one():
+    assert distributed.world_size() == 1
+    r = torch.arange(16, dtype=torch.uint8)
+    assert torch.equal(distributed.gather_records(r), r.unsqueeze(0))
+    assert distributed.all_gather_rows(torch.ones(3, 2)).shape == (3, 2)
+    assert distributed.max_over_ranks(2.5, "cpu") == 2.5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _slice_state(t, start, count):
+    """Rank's block of a global AllegroHand state (3 actor rows per environment)."""
+    out = {}
+    for k, v in t.items():
+        if v is None:
+            out[k] = None
+        elif k == "root_state_tensor":
+            out[k] = v[3 * start:3 * (start + count)].copy()
+        elif k in ("object_indices", "goal_object_indices"):
+            out[k] = v[start:start + count] - 3 * start
+        elif k in ("consecutive_successes", "workspace"):
+            out[k] = v.copy()
+        else:
+            out[k] = v[start:start + count].copy()
+    return out
+
+
+def _allegro_rank(rank, world, port, n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    got = distributed.init_from_env(backend="gloo")
+    assert got == (rank, rank, world) and distributed.world_size() == world
+    oracle.set_num_threads(2)
+    full = {k: (v.numpy().copy() if v is not None else None)
+            for k, v in synthetic.allegro_state(n, 31, "cpu", "full_state", True).items()}
+    full["rand"] = np.random.default_rng(1).random((n, 45), dtype=np.float32)
+    start, count = distributed.env_shard(n, rank, world)
+    mine = _slice_state(full, start, count)
+    p = synthetic.allegro_params("full_state")
+    for step in range(3):
+        oracle.allegro_pre_physics(p, mine, count)
+        oracle.allegro_post_physics_shard(p, mine, count)
+        rec = torch.from_numpy(mine["workspace"].view(np.uint8)[:16].copy())
+        records = distributed.gather_records(rec)
+        assert records.shape == (world, 16)
+        oracle.allegro_finalize_shards(p, mine, records.numpy())
+        assert not mine["workspace"].view(np.uint8)[:16].any()
+    # imitation batches: per-rank rows concatenated in rank order
+    rows = distributed.all_gather_rows(torch.full((4, 3), float(rank)))
+    assert rows.shape == (4 * world, 3) and torch.equal(rows[::4, 0], torch.arange(world, dtype=torch.float32))
+    assert distributed.max_over_ranks(float(rank), "cpu") == world - 1
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), start=start, count=count,
+             **{k: v for k, v in mine.items() if v is not None})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allegro_sharded_over_two_gloo_ranks_equals_one_shard(tmp_path):
+    n, world = 4001, 2
+    mp.spawn(_allegro_rank, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    full = {k: (v.numpy().copy() if v is not None else None)
+            for k, v in synthetic.allegro_state(n, 31, "cpu", "full_state", True).items()}
+    full["rand"] = np.random.default_rng(1).random((n, 45), dtype=np.float32)
+    p = synthetic.allegro_params("full_state")
+    for step in range(3):
+        oracle.allegro_pre_physics(p, full, n)
+        oracle.allegro_post_physics(p, full, n)
+    assert full["reset"].sum() > 0
+    cons = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        s, c = int(z["start"]), int(z["count"])
+        for k in ("obs", "states", "rew", "reset", "reset_goal", "progress", "successes", "goal_states", "dof_state",
+                  "cur_targets"):
+            assert np.array_equal(z[k].view(np.uint8), full[k][s:s + c].view(np.uint8)), (r, k)
+        assert np.array_equal(z["root_state_tensor"], full["root_state_tensor"][3 * s:3 * (s + c)])
+        cons.append(z["consecutive_successes"].copy())
+    assert np.array_equal(cons[0].view(np.uint32), cons[1].view(np.uint32))  # same bits on every rank
+    assert cons[0][0] != 0.0
+    np.testing.assert_allclose(cons[0], full["consecutive_successes"], rtol=1e-6)

@@ -58,3 +58,42 @@ def test_allegro_vs_oracle(n, obs_type, asym):
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew step %d" % step)
         H.assert_close(t["consecutive_successes"].cpu().numpy(), ref["consecutive_successes"], what="cons")
         assert float(t["workspace"].abs().sum()) == 0.0  # re-zeroed by the library
+
+
+def test_allegro_two_shards_equal_one_on_device():
+    """Two environment shards + gathered records + finalize == the unsharded call."""
+    from isaacgym_amd import distributed
+    n = 50000
+    p = synthetic.allegro_params("full_state", seed=1, rng_offset=2)
+    full = synthetic.allegro_state(n, 8, DEV, "full_state")
+    full["rand"] = torch.rand(n, 45, device=DEV)
+    full["consecutive_successes"].fill_(0.25)
+    shards = []
+    for r in range(2):
+        s, c = distributed.env_shard(n, r, 2)
+        sh = {}
+        for k, v in full.items():
+            if v is None:
+                sh[k] = None
+            elif k == "root_state_tensor":
+                sh[k] = v[3 * s:3 * (s + c)].clone()
+            elif k in ("object_indices", "goal_object_indices"):
+                sh[k] = (v[s:s + c] - 3 * s).contiguous()
+            elif k in ("consecutive_successes", "workspace"):
+                sh[k] = v.clone()
+            else:
+                sh[k] = v[s:s + c].clone()
+        shards.append((s, c, sh))
+    ops.allegro_post_physics(p, full, n)
+    for _, c, sh in shards:
+        ops.allegro_post_physics_shard(p, sh, c)
+    records = torch.cat([sh["workspace"].view(torch.uint8)[:16] for _, _, sh in shards]).contiguous()
+    assert int(records.view(torch.int64)[0]) + int(records.view(torch.int64)[2]) == int(full["reset"].sum())
+    for s, c, sh in shards:
+        ops.allegro_finalize_shards(p, sh, records)
+        assert float(sh["workspace"].abs().sum()) == 0.0
+        for k in ("obs", "rew", "reset", "reset_goal", "progress", "successes"):
+            assert torch.equal(sh[k], full[k][s:s + c]), k
+        H.assert_close(sh["consecutive_successes"].cpu().numpy(), full["consecutive_successes"].cpu().numpy(),
+                       rtol=1e-6, what="consecutive_successes")
+    assert torch.equal(shards[0][2]["consecutive_successes"], shards[1][2]["consecutive_successes"])
