@@ -267,61 +267,206 @@ __device__ __forceinline__ void env_obs_from_global(const igx_amp_params &p, con
     amp_obs_full(load_v(r), load_q(r + 3), load_v(r + 7), load_v(r + 10), ds, ds + 1, 2, key, p.local_root_obs != 0, obs);
 }
 
+// Observation of one environment assembled in place in its LDS row: on entry the row
+// holds the joint velocities at their final columns [65,93) and the joint positions
+// parked at [37,65); joint j's 1 or 6 columns at 13 + DOF_OBS_OFFSETS[j] never reach the
+// position of a joint that is still to be read (DOF_OBS_OFFSETS[j+1] - DOF_OFFSETS[j+1] <= 24).
+constexpr int POS_PARK = 37;
+__device__ __forceinline__ void amp_obs_inplace(const float (&rr)[13], const float *key, bool local_root_obs, float *row)
+{
+    const f3 root_pos{rr[0], rr[1], rr[2]};
+    f4 heading_rot;
+    float c[13];
+    root_obs(root_pos, f4{rr[3], rr[4], rr[5], rr[6]}, f3{rr[7], rr[8], rr[9]}, f3{rr[10], rr[11], rr[12]},
+             local_root_obs, heading_rot, c);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) row[i] = c[i];
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+        const int off = DOF_OFFSETS[j], size = DOF_OFFSETS[j + 1] - off;
+        float d[3] = {row[POS_PARK + off], 0.0f, 0.0f}, o6[6];
+        if (size == 3) {
+            d[1] = row[POS_PARK + off + 1];
+            d[2] = row[POS_PARK + off + 2];
+        }
+        joint_obs(d, size, o6);
+        float *dst = row + 13 + DOF_OBS_OFFSETS[j];
+        dst[0] = o6[0];
+        if (size == 3) { dst[1] = o6[1]; dst[2] = o6[2]; dst[3] = o6[3]; dst[4] = o6[4]; dst[5] = o6[5]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const f3 l = quat_rotate<false>(heading_rot, f3{key[3 * k] - root_pos.x, key[3 * k + 1] - root_pos.y,
+                                                        key[3 * k + 2] - root_pos.z});
+        row[93 + 3 * k] = l.x; row[94 + 3 * k] = l.y; row[95 + 3 * k] = l.z;
+    }
+}
+
+// AMP history of a group of G environments (rows of KK * 105 floats, newest first):
+// every slot moves one place back, slot 0 takes the new observation from the LDS tile.
+// All of the group's source chunks are in registers before its first store; a row is
+// read and written by its own group only.
+template <int KK, int G>
+__device__ __forceinline__ void shift_history(float *__restrict__ amp, const float *s_tile, int env0, int lane)
+{
+    constexpr int ROW = KK * NO;
+    constexpr int N4 = G * ROW / 4;
+    constexpr int ITERS = (N4 + WAVE - 1) / WAVE;
+    static_assert((G * ROW) % 4 == 0, "group slab must be whole 16-byte chunks");
+    float *slab = amp + (int64_t)env0 * ROW;
+    v4f old[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        int k = lane + it * WAVE;
+        k = k < N4 ? k : N4 - 1;
+        // position g of the slab takes the old value NO floats earlier (same row) unless it is in slot 0;
+        // a chunk that lies in slot 0 entirely has nothing to fetch
+        const int g = 4 * k, r_first = g % ROW, r_last = (g + 3) % ROW;
+        const bool any_old = r_first >= NO || r_last >= NO;
+        old[it] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        if (it == 0 && g < NO) {  // would start before the slab: element-wise
+            if (g + 3 >= NO) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = g + i >= NO ? __builtin_nontemporal_load(slab + g + i - NO) : 0.0f;
+                old[it] = v4f{o[0], o[1], o[2], o[3]};
+            }
+        } else if (any_old) {
+            old[it] = ld_stream_u(slab + g - NO);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every load has returned before the stores below
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int k = lane + it * WAVE;
+        if ((it + 1) * WAVE <= N4 || k < N4) {
+            const float o[4] = {old[it].x, old[it].y, old[it].z, old[it].w};
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = 4 * k + i;
+                const int env = g / ROW, r = g - env * ROW;
+                v[i] = r < NO ? s_tile[(env0 + env) * NO + r] : o[i];
+            }
+            st_stream(reinterpret_cast<v4f *>(slab) + k, v4f{v[0], v[1], v[2], v[3]});
+        }
+    }
+}
+
+// KK = compile-time number of history steps (0: any, slower path)
+template <int KK>
 __global__ __launch_bounds__(WAVE) void amp_step_kernel(const igx_amp_params p, const igx_amp_buffers b, int64_t n)
 {
-    __shared__ __align__(16) float s_tile[WAVE * NO];       // new observation rows
-    __shared__ __align__(16) float s_in[WAVE * 2 * ND];     // dof_state slab, then the old newest AMP slots
-    __shared__ __align__(16) float s_root[WAVE * 13];
-    __shared__ unsigned s_contact[WAVE];
-    static_assert(WAVE * 2 * ND >= WAVE * 13, "slab");
+    constexpr int BODY_ROW = NB * 13;  // 195 floats per environment
+    constexpr int HALF = WAVE / 2;
+    __shared__ __align__(16) float s_tile[WAVE * NO];  // transposition scratch first, then the observation rows
+    __shared__ float s_key[WAVE * NK * 3];
+    __shared__ unsigned s_low[WAVE];
+    static_assert(HALF * BODY_ROW <= WAVE * NO, "half a tile of rigid-body rows fits the tile");
+    static_assert(WAVE * (NB * 3 + 13) <= WAVE * NO, "contact + root rows fit the tile");
     const int lane = threadIdx.x;
-    const int K = p.num_amp_obs_steps;
+    const int K = KK ? KK : p.num_amp_obs_steps;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
     const bool full = nvalid == WAVE;
     const bool live = lane < nvalid;
     const int64_t e = base + lane;
 
-    // ---- loads: root rows and dof_state slab through LDS
     int64_t prog = 0;
     if (live) prog = ld_stream(b.progress + e);
-    v4f r_root[(WAVE * 13 / 4 + WAVE - 1) / WAVE], r_dof[WAVE * 2 * ND / 4 / WAVE];
-    if (full) {
-        load_chunks<WAVE * 13 / 4>(b.root_states + base * 13, r_root, lane);
-        load_chunks<WAVE * 2 * ND / 4>(b.dof_state + base * (2 * ND), r_dof, lane);
-    }
-    s_contact[lane] = 0;
-    park_rows<13>(r_root, b.root_states + base * 13, s_root, nvalid, lane);
-    park_rows<2 * ND>(r_dof, b.dof_state + base * (2 * ND), s_in, nvalid, lane);
+    s_low[lane] = 0;
 
-    // ---- contact forces: stream the tile's [64,15,3] slab through the fall-contact predicate
+    // ---- rigid-body rows, half a tile at a time: coalesced into LDS, then lane (env, part)
+    // picks the body heights of its 8 / 7 bodies and two of the key-body positions
+    constexpr int HB4 = HALF * BODY_ROW / 4;  // 1560 chunks
+    v4f r_body[2][(HB4 + WAVE - 1) / WAVE];
+    if (full) {
+        load_chunks<HB4>(b.rigid_body_state + base * BODY_ROW, r_body[0], lane);
+        load_chunks<HB4>(b.rigid_body_state + (base + HALF) * BODY_ROW, r_body[1], lane);
+    }
+    constexpr int CF4 = WAVE * NB * 3 / 4, ROOT4 = WAVE * 13 / 4, DOF4 = WAVE * 2 * ND / 4;
+    v4f r_cf[(CF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE], r_dof[DOF4 / WAVE];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cnt = nvalid - h * HALF < 0 ? 0 : (nvalid - h * HALF > HALF ? HALF : nvalid - h * HALF);
+        if (full) {
+#pragma unroll
+            for (int it = 0; it < (HB4 + WAVE - 1) / WAVE; ++it) {
+                const int k = lane + it * WAVE;
+                if ((it + 1) * WAVE <= HB4 || k < HB4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_body[h][it];
+            }
+        } else {
+            for (int i = lane; i < cnt * BODY_ROW; i += WAVE) s_tile[i] = b.rigid_body_state[(base + h * HALF) * BODY_ROW + i];
+        }
+        if (h == 0 && full) {  // next inputs on their way while the rows are picked apart
+            load_chunks<CF4>(b.contact_forces + base * (NB * 3), r_cf, lane);
+            load_chunks<ROOT4>(b.root_states + base * 13, r_root, lane);
+        }
+        if (h == 1 && full) load_chunks<DOF4>(b.dof_state + base * (2 * ND), r_dof, lane);
+        wave_sync();
+        const int el = lane & (HALF - 1), part = lane >> 5;
+        if (el < cnt) {
+            const float *row = s_tile + el * BODY_ROW;
+            bool low = false;
+            const int b0 = part ? 8 : 0, b1 = part ? NB : 8;
+            for (int body = b0; body < b1; ++body)
+                low |= (row[body * 13 + 2] < p.termination_height) && !is_contact_body(p, body);
+            if (low) atomicOr(&s_low[h * HALF + el], 1u);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int key = 2 * part + kk;
+                const float *kp = row + p.key_body_ids[key] * 13;
+                float *dst = s_key + (h * HALF + el) * (NK * 3) + key * 3;
+                dst[0] = kp[0]; dst[1] = kp[1]; dst[2] = kp[2];
+            }
+        }
+        wave_sync();
+    }
+
+    // ---- contact forces and root rows through the tile: lane i takes environment i's rows
+    park_rows<NB * 3>(r_cf, b.contact_forces + base * (NB * 3), s_tile, nvalid, lane);
+    park_rows<13>(r_root, b.root_states + base * 13, s_tile + WAVE * NB * 3, nvalid, lane);
+    wave_sync();
+    float rr[13];
+    bool fall_contact = false;
     {
-        const float *cf = b.contact_forces + base * (NB * 3);
-        const int count = nvalid * NB * 3;
-        for (int i = lane; i < count; i += WAVE) {
-            const float v = ld_stream(cf + i);
-            const int env = i / (NB * 3), body = (i - env * NB * 3) / 3;
-            if (v > 0.1f && !is_contact_body(p, body)) atomicOr(&s_contact[env], 1u);
+        const float *cf = s_tile + lane * (NB * 3);
+        for (int body = 0; body < NB; ++body) {
+            const bool hit = cf[3 * body] > 0.1f || cf[3 * body + 1] > 0.1f || cf[3 * body + 2] > 0.1f;
+            fall_contact |= hit && !is_contact_body(p, body);
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) rr[i] = s_tile[WAVE * NB * 3 + lane * 13 + i];
+    }
+    wave_sync();
+
+    // ---- dof_state: velocities to their final columns, positions parked inside the row
+    if (full) {
+#pragma unroll
+        for (int it = 0; it < DOF4 / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            const int pr = 2 * k;  // dof pair index within the tile: both dofs belong to one environment (ND even)
+            const int env = pr / ND, j = pr - env * ND;
+            float *row = s_tile + env * NO;
+            row[POS_PARK + j] = r_dof[it].x; row[POS_PARK + j + 1] = r_dof[it].z;
+            row[65 + j] = r_dof[it].y; row[65 + j + 1] = r_dof[it].w;
+        }
+    } else {
+        for (int i = lane; i < nvalid * ND; i += WAVE) {
+            const int env = i / ND, j = i - env * ND;
+            const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * ND + i];
+            s_tile[env * NO + POS_PARK + j] = pv.x;
+            s_tile[env * NO + 65 + j] = pv.y;
         }
     }
     wave_sync();
 
-    // ---- per-env: observation, reset decision
+    // ---- per-env: observation in place, reward, reset decision
     if (live) {
-        const float *rr = s_root + lane * 13;
-        f3 key[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) key[k] = load_v(b.rigid_body_state + (e * NB + p.key_body_ids[k]) * 13);
-        bool fall_height = false;
-        for (int body = 0; body < NB; ++body) {
-            const float z = b.rigid_body_state[(e * NB + body) * 13 + 2];
-            fall_height |= (z < p.termination_height) && !is_contact_body(p, body);
-        }
-        amp_obs_full(load_v(rr), load_q(rr + 3), load_v(rr + 7), load_v(rr + 10), s_in + lane * 2 * ND,
-                     s_in + lane * 2 * ND + 1, 2, key, p.local_root_obs != 0, s_tile + lane * NO);
+        amp_obs_inplace(rr, s_key + lane * (NK * 3), p.local_root_obs != 0, s_tile + lane * NO);
         prog += 1;
         int64_t terminated = 0;
-        if (p.enable_early_termination && s_contact[lane] != 0 && fall_height && prog > 1) terminated = 1;
+        if (p.enable_early_termination && fall_contact && s_low[lane] != 0 && prog > 1) terminated = 1;
         st_stream(b.rew + e, 1.0f);
         st_stream(b.reset + e, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
         st_stream(b.terminate + e, terminated);
@@ -336,20 +481,22 @@ __global__ __launch_bounds__(WAVE) void amp_step_kernel(const igx_amp_params p, 
         for (int i = lane; i < nvalid * NO; i += WAVE) b.obs[base * NO + i] = s_tile[i];
     }
 
-    // ---- AMP history: slot k+1 <- slot k (newest first), slot 0 <- new observation.
-    // Old slots are parked in LDS one slot at a time, oldest destination first.
+    // ---- AMP history: slot k+1 <- slot k (newest first), slot 0 <- new observation
     float *amp = b.amp_obs + base * K * NO;
-    for (int k = K - 2; k >= 0; --k) {
-        // read slot k of every env of the tile, write it to slot k+1
+    if (KK != 0 && full && dev_aligned16(b.amp_obs)) {
+        constexpr int G = 16;
+#pragma unroll 1
+        for (int g0 = 0; g0 < WAVE; g0 += G) shift_history<KK ? KK : 2, G>(amp, s_tile, g0, lane);
+    } else {
+        for (int k = K - 2; k >= 0; --k)
+            for (int i = lane; i < nvalid * NO; i += WAVE) {
+                const int env = i / NO, c = i - env * NO;
+                amp[(env * K + k + 1) * NO + c] = amp[(env * K + k) * NO + c];
+            }
         for (int i = lane; i < nvalid * NO; i += WAVE) {
             const int env = i / NO, c = i - env * NO;
-            const float v = amp[(env * K + k) * NO + c];
-            amp[(env * K + k + 1) * NO + c] = v;
+            amp[(env * K) * NO + c] = s_tile[i];
         }
-    }
-    for (int i = lane; i < nvalid * NO; i += WAVE) {
-        const int env = i / NO, c = i - env * NO;
-        amp[(env * K) * NO + c] = s_tile[i];
     }
 }
 
@@ -466,8 +613,14 @@ extern "C" int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buff
     int rc = check_amp(p, b, n, "igx_humanoid_amp_step");
     if (rc != IGX_OK || n == 0) return rc;
     if (!b->contact_forces || !b->rew) return fail(IGX_E_NULL, "igx_humanoid_amp_step: contact_forces / rew is NULL");
-    hipLaunchKernelGGL(amp_step_kernel, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0,
-                       static_cast<hipStream_t>(stream), *p, *b, n);
+    const dim3 grid((unsigned)((n + WAVE - 1) / WAVE));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (p->num_amp_obs_steps) {
+    case 2: hipLaunchKernelGGL(amp_step_kernel<2>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
+    case 3: hipLaunchKernelGGL(amp_step_kernel<3>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
+    case 4: hipLaunchKernelGGL(amp_step_kernel<4>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
+    default: hipLaunchKernelGGL(amp_step_kernel<0>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
+    }
     return launch_status("igx_humanoid_amp_step");
 }
 

@@ -13,6 +13,10 @@ constexpr int WAVE = 64;
 using v4f = float __attribute__((ext_vector_type(4)));
 using v2f = float __attribute__((ext_vector_type(2)));
 
+// 16-byte vector at a 4-byte-aligned address (global memory takes dword-aligned
+// multi-dword accesses): rows whose length is not a multiple of 4 floats
+using v4f_u = v4f __attribute__((aligned(4)));
+
 // Streaming (non-temporal) global accesses: every byte of this path is touched
 // exactly once per step, so nothing is worth keeping in L2; on MI355X the nt
 // forms stream ~20 % faster than default-policy loads / stores here.
@@ -20,6 +24,11 @@ template <class T>
 __device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
 template <class T>
 __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+
+__device__ __forceinline__ v4f ld_stream_u(const float *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const v4f_u *>(p));
+}
 
 __device__ __forceinline__ bool dev_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of every entry point besides the headline Ant step:
+achieved algorithmic GB/s (HBM-bound kernels) or samples/s (motion library).
+Usage: PYTHONPATH=. python tools/bench_tasks.py [--envs N] [--steps K] [names...]"""
+import argparse
+import json
+import sys
+
+import numpy as np
+import torch
+
+from isaacgym_amd import ops, synthetic
+
+DEV = "cuda:0"
+# algorithmic bytes per env-step: every input read once, every output written once
+BYTES = dict(cartpole=68, ant=556, humanoid=940, allegro_post=748, allegro_pre=16 * 4 * 4 + 16,
+             amp=2272, amp_k2_full_rows=2960, tail_ant=60 * 8 + 17)
+
+
+def timed(fn, steps, warmup=10):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        fn(warmup + i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=1 << 20)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("names", nargs="*")
+    a = ap.parse_args()
+    n = a.envs
+    want = set(a.names)
+    res = {}
+
+    def report(name, us, bytes_per_env=None, units=n):
+        r = {"us": round(us, 2), "units_per_s": units / us * 1e6}
+        if bytes_per_env:
+            r["GBps"] = round(units * bytes_per_env / us / 1e3, 1)
+            r["frac_of_8TBps"] = round(r["GBps"] / 8000.0, 3)
+        res[name] = r
+        print(name, json.dumps(r), flush=True)
+
+    def on(name):
+        return not want or name in want
+
+    if on("cartpole"):
+        p = synthetic.cartpole_params(1, 0)
+        sets = [synthetic.cartpole_state(n, s, DEV) for s in range(4)]
+        report("cartpole", timed(lambda i: ops.cartpole_step(p, sets[i % 4], n), a.steps), BYTES["cartpole"])
+    for name, spec, fn in (("ant", synthetic.ANT, ops.ant_step), ("humanoid", synthetic.HUMANOID, ops.humanoid_step)):
+        if on(name):
+            p = synthetic.loco_params(spec, 1, 0)
+            sets = [synthetic.loco_state(spec, n, s, DEV) for s in range(4)]
+            report(name, timed(lambda i: fn(p, sets[i % 4], n), a.steps), BYTES[name])
+            del sets
+    if on("allegro"):
+        p = synthetic.allegro_params("full_state", 1, 0)
+        sets = [synthetic.allegro_state(n, s, DEV) for s in range(3)]
+        report("allegro_post", timed(lambda i: ops.allegro_post_physics(p, sets[i % 3], n), a.steps), BYTES["allegro_post"])
+        report("allegro_pre", timed(lambda i: ops.allegro_pre_physics(p, sets[i % 3], n), a.steps), BYTES["allegro_pre"])
+        del sets
+    if on("amp"):
+        for K in (2,):
+            p = synthetic.amp_params(K)
+            sets = [synthetic.amp_state(n, s, DEV, K) for s in range(2)]
+            report("amp_step_K%d" % K, timed(lambda i: ops.humanoid_amp_step(p, sets[i % 2], n), a.steps), BYTES["amp"])
+            del sets
+    if on("tail"):
+        obs = torch.randn(n, 60, device=DEV)
+        out = torch.empty_like(obs)
+        prog = torch.randint(0, 1000, (n,), device=DEV)
+        rst = torch.randint(0, 2, (n,), device=DEV)
+        to = torch.zeros(n, dtype=torch.bool, device=DEV)
+        report("tail_ant", timed(lambda i: ops.vec_task_tail(obs, out, 5.0, prog, rst, to, 1000), a.steps), BYTES["tail_ant"])
+    if on("motion"):
+        sys.path.insert(0, ".")
+        from tests import helpers as H
+        g = H.load_golden("motion")
+        tabs = {k: torch.from_numpy(v).to(DEV) for k, v in H.motion_tabs_from_golden(g).items()}
+        tables = ops.motion_tables(tabs)
+        for m in (1024, 1 << 16, 1 << 20):
+            rng = np.random.default_rng(0)
+            ids = torch.from_numpy(rng.integers(0, 2, m).astype(np.int64)).to(DEV)
+            L = tabs["motion_length"][ids]
+            times = (torch.rand(m, device=DEV, dtype=torch.float64) * L).contiguous()
+            f = dict(dtype=torch.float32, device=DEV)
+            out = dict(root_pos=torch.empty(m, 3, **f), root_rot=torch.empty(m, 4, **f), dof_pos=torch.empty(m, 28, **f),
+                       root_vel=torch.empty(m, 3, **f), root_ang_vel=torch.empty(m, 3, **f),
+                       dof_vel=torch.empty(m, 28, **f), key_pos=torch.empty(m, 4, 3, **f))
+            report("motion_state_%d" % m, timed(lambda i: ops.motion_state(tables, ids, times, out), a.steps), None, m)
+            o = torch.empty(m, 105, **f)
+            report("motion_amp_obs_%d" % m, timed(lambda i: ops.motion_amp_obs(tables, ids, times, False, o), a.steps), None, m)
+    print("RESULT " + json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
