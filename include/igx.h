@@ -190,6 +190,9 @@ typedef struct igx_allegro_params {
     uint64_t seed, rng_offset;
 } igx_allegro_params;
 
+/* scratch for the cross-environment reduction: one 16-byte record per 64 environments + the total */
+#define IGX_ALLEGRO_WORKSPACE_BYTES(n_envs) (16 * (((int64_t)(n_envs) + 63) / 64 + 1))
+
 typedef struct igx_allegro_buffers {
     float *dof_state;                 /* [N,16,2] in (post) / in-out (pre: reset envs) */
     const float *dof_force;           /* [N,16]; needed for the 88-column layouts */
@@ -209,7 +212,8 @@ typedef struct igx_allegro_buffers {
     int64_t *randomize;               /* [N] += 1 in post; may be NULL */
     float *successes;                 /* [N] in/out */
     float *consecutive_successes;     /* [1] in/out */
-    void *workspace;                  /* 64 bytes, zero before the first call; the library re-zeroes it */
+    void *workspace;                  /* IGX_ALLEGRO_WORKSPACE_BYTES(n_envs) of device scratch, 16-byte aligned,
+                                         contents irrelevant on entry (per-tile partial sums of the reduction) */
 } igx_allegro_buffers;
 
 int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
@@ -222,8 +226,8 @@ int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buff
  * averages over ALL environments, so a shard stops after leaving its 16-byte
  * record {uint64 num_resets; double sum(successes * resets)} at b->workspace;
  * the caller gathers the records of all shards (rank order) and every rank
- * calls igx_allegro_finalize_shards, which adds them in index order, updates
- * consecutive_successes[0] and re-zeroes b->workspace. */
+ * calls igx_allegro_finalize_shards, which adds them in index order and updates
+ * consecutive_successes[0]. */
 #define IGX_ALLEGRO_SHARD_RECORD_BYTES 16
 int igx_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n_envs,
                                    igx_stream_t stream);

@@ -241,9 +241,13 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
             succ = ld_stream(b.successes + e);
             if (b.randomize) rnd = ld_stream(b.randomize + e);
         }
+        // gathered actor row: three 16-byte loads at a 4-byte-aligned address and one scalar
         const float *orow = b.root_state_tensor + b.object_indices[e] * 13;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) obj[i] = orow[i];
+        const v4f o0 = ld_stream_u(orow), o1 = ld_stream_u(orow + 4), o2 = ld_stream_u(orow + 8);
+        obj[0] = o0.x; obj[1] = o0.y; obj[2] = o0.z; obj[3] = o0.w;
+        obj[4] = o1.x; obj[5] = o1.y; obj[6] = o1.z; obj[7] = o1.w;
+        obj[8] = o2.x; obj[9] = o2.y; obj[10] = o2.z; obj[11] = o2.w;
+        obj[12] = __builtin_nontemporal_load(orow + 12);
     }
     if (full) {
         load_chunks<WAVE * AD * 2 / 4>(b.dof_state + base * (2 * AD), r_dof, lane);
@@ -354,10 +358,10 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
             f += __shfl_xor(f, off);
             cnt += __shfl_xor(cnt, off);
         }
-        if (lane == 0 && cnt != 0) {
-            AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
-            atomicAdd(&ws->num_resets, (unsigned long long)cnt);
-            atomicAdd(&ws->finished, (double)f);
+        if (lane == 0) {  // this tile's record; record 0 is reserved for the reduced sums
+            AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace) + 1 + blockIdx.x;
+            ws->num_resets = (unsigned long long)cnt;
+            ws->finished = (double)f;
         }
     }
     wave_sync();
@@ -366,13 +370,42 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         drain_rows<NOBS>(b.states + base * NOBS, s_tile, nvalid, lane);
 }
 
+// The tiles' records are added in a fixed order (thread t takes records t, t + 1024, ...,
+// then a binary tree over the threads), so the sums do not depend on scheduling.
+// Result -> record 0 of the workspace.
+__global__ __launch_bounds__(1024) void allegro_reduce_kernel(AllegroWorkspace *ws, int64_t num_tiles)
+{
+    __shared__ unsigned long long s_cnt[1024];
+    __shared__ double s_fin[1024];
+    const int t = threadIdx.x;
+    unsigned long long cnt = 0;
+    double fin = 0.0;
+    for (int64_t i = t; i < num_tiles; i += 1024) {
+        cnt += ws[1 + i].num_resets;
+        fin += ws[1 + i].finished;
+    }
+    s_cnt[t] = cnt;
+    s_fin[t] = fin;
+    __syncthreads();
+    for (int half = 512; half > 0; half >>= 1) {
+        if (t < half) {
+            s_cnt[t] += s_cnt[t + half];
+            s_fin[t] += s_fin[t + half];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        ws[0].num_resets = s_cnt[0];
+        ws[0].finished = s_fin[0];
+    }
+}
+
 // :714-719 consecutive_successes update from the two global sums: the records of
-// all shards (this device's own workspace when there is one shard) are added in
-// index order, so every rank of a sharded run computes the same bits
+// all shards (record 0 of this device's own workspace when there is one shard) are
+// added in index order, so every rank of a sharded run computes the same bits
 __global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
                                         const AllegroWorkspace *__restrict__ records, int num_records)
 {
-    AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
     unsigned long long num_resets = 0;
     double finished = 0.0;
     for (int i = 0; i < num_records; ++i) {
@@ -384,8 +417,6 @@ __global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_al
         const float cons = b.consecutive_successes[0];
         b.consecutive_successes[0] = p.av_factor * fin / (float)(long long)num_resets + p.one_minus_av_factor * cons;
     }
-    ws->num_resets = 0;
-    ws->finished = 0.0;
 }
 
 static int check_allegro(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, bool post,
@@ -472,7 +503,9 @@ static int allegro_post_launch(const igx_allegro_params *p, const igx_allegro_bu
         rc = launch_status("igx_allegro_post_physics(states)");
         if (rc != IGX_OK) return rc;
     }
-    return IGX_OK;
+    hipLaunchKernelGGL(allegro_reduce_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<AllegroWorkspace *>(b->workspace),
+                       (int64_t)tiles);
+    return launch_status("igx_allegro_post_physics(reduce)");
 }
 
 extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
@@ -500,10 +533,9 @@ extern "C" int igx_allegro_finalize_shards(const igx_allegro_params *p, const ig
 {
     if (!p || !b) return fail(IGX_E_NULL, "igx_allegro_finalize_shards: params/buffers struct is NULL");
     if (num_shards < 1 || num_shards > 65536) return fail(IGX_E_SIZE, "igx_allegro_finalize_shards: num_shards %d", num_shards);
-    if (!records || !b->consecutive_successes || !b->workspace)
-        return fail(IGX_E_NULL, "igx_allegro_finalize_shards: records / consecutive_successes / workspace is NULL");
-    if (!aligned16(records) || !aligned16(b->workspace))
-        return fail(IGX_E_ALIGN, "igx_allegro_finalize_shards: records and workspace must be 16-byte aligned");
+    if (!records || !b->consecutive_successes)
+        return fail(IGX_E_NULL, "igx_allegro_finalize_shards: records / consecutive_successes is NULL");
+    if (!aligned16(records)) return fail(IGX_E_ALIGN, "igx_allegro_finalize_shards: records must be 16-byte aligned");
     hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), *p, *b,
                        static_cast<const AllegroWorkspace *>(records), (int)num_shards);
     return launch_status("igx_allegro_finalize_shards");

@@ -141,6 +141,11 @@ def allegro_params(obs_type="full_state", seed=0, rng_offset=0, **over):
     return _abi.AllegroParams(**kw)
 
 
+def allegro_workspace_floats(n):
+    """IGX_ALLEGRO_WORKSPACE_BYTES(n) / 4."""
+    return 4 * ((n + 63) // 64 + 1)
+
+
 def allegro_state(n, seed, device, obs_type="full_state", asymmetric=False):
     """name->tensor dict of igx_allegro_buffers; ~1 % of envs start within the
     success tolerance, object/goal distance up to 0.3 m (fallDistance 0.24)."""
@@ -190,7 +195,7 @@ def allegro_state(n, seed, device, obs_type="full_state", asymmetric=False):
         randomize=torch.zeros(n, dtype=torch.int64, device=device),
         successes=torch.randint(0, 5, (n,), generator=gen, device=device).float(),
         consecutive_successes=torch.zeros(1, device=device),
-        workspace=torch.zeros(16, device=device))
+        workspace=torch.empty(allegro_workspace_floats(n), device=device))
 
 
 # ---------------------------------------------------------------- HumanoidAMP

@@ -122,7 +122,7 @@ class AllegroHand(VecTask):
         self.seed = int(seed)
         self.reset_rand = None  # optional [N,45] pre-drawn uniforms
         self._draws = 0
-        self._workspace = torch.zeros(16, device=dev)  # reduction scratch, kept zero by the library
+        self._workspace = torch.empty(4 * ((n + 63) // 64 + 1), device=dev)  # reduction scratch (16 B per tile + total)
         tol = self.success_tolerance * (2.0 if self.ignore_z else 1.0)
         self._success_c = success_threshold_c(tol)
         av32 = float(torch.tensor(self.av_factor, dtype=torch.float32))

@@ -848,7 +848,6 @@ int orc_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_b
                                 int32_t num_shards)
 {
     allegro_finalize(p, b, (const allegro_record *)records, num_shards);
-    memset(b->workspace, 0, sizeof(allegro_record));
     return 0;
 }
 

@@ -76,7 +76,6 @@ def _allegro_rank(rank, world, port, n, outdir):
         records = distributed.gather_records(rec)
         assert records.shape == (world, 16)
         oracle.allegro_finalize_shards(p, mine, records.numpy())
-        assert not mine["workspace"].view(np.uint8)[:16].any()
     # imitation batches: per-rank rows concatenated in rank order
     rows = distributed.all_gather_rows(torch.full((4, 3), float(rank)))
     assert rows.shape == (4 * world, 3) and torch.equal(rows[::4, 0], torch.arange(world, dtype=torch.float32))

@@ -57,7 +57,6 @@ def test_allegro_vs_oracle(n, obs_type, asym):
             H.assert_close(t["states"].cpu().numpy(), ref["states"], what="states step %d" % step)
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew step %d" % step)
         H.assert_close(t["consecutive_successes"].cpu().numpy(), ref["consecutive_successes"], what="cons")
-        assert float(t["workspace"].abs().sum()) == 0.0  # re-zeroed by the library
 
 
 def test_allegro_two_shards_equal_one_on_device():
@@ -79,7 +78,9 @@ def test_allegro_two_shards_equal_one_on_device():
                 sh[k] = v[3 * s:3 * (s + c)].clone()
             elif k in ("object_indices", "goal_object_indices"):
                 sh[k] = (v[s:s + c] - 3 * s).contiguous()
-            elif k in ("consecutive_successes", "workspace"):
+            elif k == "workspace":
+                sh[k] = torch.full_like(v, float("nan"))  # scratch needs no initialisation
+            elif k == "consecutive_successes":
                 sh[k] = v.clone()
             else:
                 sh[k] = v[s:s + c].clone()
@@ -91,7 +92,6 @@ def test_allegro_two_shards_equal_one_on_device():
     assert int(records.view(torch.int64)[0]) + int(records.view(torch.int64)[2]) == int(full["reset"].sum())
     for s, c, sh in shards:
         ops.allegro_finalize_shards(p, sh, records)
-        assert float(sh["workspace"].abs().sum()) == 0.0
         for k in ("obs", "rew", "reset", "reset_goal", "progress", "successes"):
             assert torch.equal(sh[k], full[k][s:s + c]), k
         H.assert_close(sh["consecutive_successes"].cpu().numpy(), full["consecutive_successes"].cpu().numpy(),
