@@ -37,12 +37,22 @@ def test_struct_sizes_match_header():
     import tempfile
     src = r'''
 #include <stdio.h>
+#include <stddef.h>
 #include "igx.h"
 int main(void){
   printf("CartpoleParams %zu\n", sizeof(igx_cartpole_params));
   printf("CartpoleBuffers %zu\n", sizeof(igx_cartpole_buffers));
   printf("LocoParams %zu\n", sizeof(igx_loco_params));
   printf("LocoBuffers %zu\n", sizeof(igx_loco_buffers));
+  printf("AllegroParams %zu\n", sizeof(igx_allegro_params));
+  printf("AllegroBuffers %zu\n", sizeof(igx_allegro_buffers));
+  printf("MotionTables %zu\n", sizeof(igx_motion_tables));
+  printf("MotionStateOut %zu\n", sizeof(igx_motion_state_out));
+  printf("AmpParams %zu\n", sizeof(igx_amp_params));
+  printf("AmpBuffers %zu\n", sizeof(igx_amp_buffers));
+  printf("VecTaskTail %zu\n", sizeof(igx_vec_task_tail));
+  printf("off_seed %zu\n", offsetof(igx_allegro_params, seed));
+  printf("off_clip %zu\n", offsetof(igx_vec_task_tail, clip_obs));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -53,7 +63,12 @@ int main(void){
         out = subprocess.check_output([exe]).decode()
     for line in out.strip().splitlines():
         name, size = line.split()
-        assert ctypes.sizeof(getattr(_abi, name)) == int(size), name
+        if name == "off_seed":
+            assert _abi.AllegroParams.seed.offset == int(size)
+        elif name == "off_clip":
+            assert _abi.VecTaskTail.clip_obs.offset == int(size)
+        else:
+            assert ctypes.sizeof(getattr(_abi, name)) == int(size), name
 
 
 def test_null_arguments_are_rejected_without_a_gpu():
@@ -66,3 +81,22 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert lib.igx_ant_step(ctypes.byref(p), ctypes.byref(b), -1, None) == _abi.IGX_E_SIZE
     assert lib.igx_ant_step(ctypes.byref(p), ctypes.byref(b), 16, None) == _abi.IGX_E_NULL
     assert lib.igx_humanoid_step(ctypes.byref(p), ctypes.byref(b), 16, None) == _abi.IGX_E_PARAM
+
+
+def test_every_entry_point_rejects_null_structs():
+    lib = _lib.lib()
+    for name in ("igx_cartpole_step", "igx_humanoid_step", "igx_allegro_pre_physics", "igx_allegro_post_physics",
+                 "igx_allegro_post_physics_shard", "igx_humanoid_amp_step"):
+        assert getattr(lib, name)(None, None, 4, None) == _abi.IGX_E_NULL, name
+    for name in ("igx_cartpole_reset", "igx_ant_reset", "igx_humanoid_reset"):
+        assert getattr(lib, name)(None, None, None, 4, None) == _abi.IGX_E_NULL, name
+    assert lib.igx_humanoid_amp_reset(None, None, None, 4, None, None) == _abi.IGX_E_NULL
+    assert lib.igx_motion_state(None, None, None, 4, None, None) == _abi.IGX_E_NULL
+    assert lib.igx_vec_task_tail_step(None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_clamp(None, -1.0, 1.0, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_quat_mul(None, None, None, 4, None) == _abi.IGX_E_NULL
+    # empty batches are valid no-ops even with NULL pointers
+    assert lib.igx_clamp(None, -1.0, 1.0, None, 0, None) == 0
+    p = _abi.AmpParams(num_amp_obs_steps=1)
+    b = _abi.AmpBuffers()
+    assert lib.igx_humanoid_amp_step(ctypes.byref(p), ctypes.byref(b), 4, None) == _abi.IGX_E_PARAM
