@@ -57,6 +57,9 @@ const char *igx_last_error_string(void);
 typedef struct igx_cartpole_params {
     float reset_dist;             /* env.resetDist, 3.0 */
     float max_episode_length_m1;  /* max_episode_length - 1 = 499 */
+    int32_t reward_variant;       /* 0: tasks/cartpole.py:185-201; 1: tasks/cartpole_sample.py:316-335
+                                     (1 - 0.001 a^2 - 0.001|cart_vel| - 0.001|pole_vel|) */
+    int32_t reserved;
     uint64_t seed;                /* in-kernel Philox key when rand == NULL */
     uint64_t rng_offset;          /* step counter mixed into the Philox counter */
 } igx_cartpole_params;
@@ -357,6 +360,30 @@ int igx_vec_task_tail_step(const igx_vec_task_tail *t, int64_t n_envs, igx_strea
 
 /* torch.clamp(x, lo, hi) on count floats (the action clamp, tasks/base/vec_task.py:384); NaN stays NaN. */
 int igx_clamp(const float *x, float lo, float hi, float *out, int64_t count, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Trajectory recorder: the fork's sampling mode (tasks/cartpole_sample.py:99-107,
+ * :119-121, :289-293) captures selected observation columns of every
+ * environment at every step with obs.clone().cpu() and an O(T^2) torch.cat.
+ * Here a capture is a gather kernel on the producer's stream into a device
+ * staging slot, and a hipMemcpyAsync into pinned host memory on the recorder's
+ * own side stream, ordered by events; the producer never waits for the host.
+ * Host layout: [max_steps][num_cols][n_rows] fp32 (step-major), pinned.
+ * ---------------------------------------------------------------------- */
+typedef struct igx_recorder igx_recorder;
+
+/* Allocates the staging ring (ring_slots x num_cols x n_rows floats on the current
+ * device) and the pinned host buffer.  cols: column indices into a row of row_width. */
+int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t row_width, const int32_t *cols,
+                        int32_t num_cols, int32_t ring_slots, int64_t max_steps);
+/* Capture src [n_rows,row_width] (device) as the next step; asynchronous.
+ * IGX_E_SIZE once max_steps captures have been taken. */
+int igx_recorder_capture(igx_recorder *r, const float *src, igx_stream_t producer_stream);
+/* Block the host until every capture so far has landed in host memory. */
+int igx_recorder_sync(igx_recorder *r);
+int64_t igx_recorder_steps(const igx_recorder *r);
+const float *igx_recorder_host_data(const igx_recorder *r);
+int igx_recorder_destroy(igx_recorder *r);
 
 /* ------------------------------------------------------------------------
  * torch_jit_utils math, one batched call per reference function

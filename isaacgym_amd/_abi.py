@@ -41,6 +41,7 @@ class _Struct(C.Structure):
 
 class CartpoleParams(_Struct):
     _fields_ = [("reset_dist", f32), ("max_episode_length_m1", f32),
+                ("reward_variant", i32), ("reserved", i32),
                 ("seed", u64), ("rng_offset", u64)]
 
 

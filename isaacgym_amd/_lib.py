@@ -35,6 +35,15 @@ SYMBOLS = {
 }
 SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])
+# trajectory recorder
+SYMBOLS.update({
+    "igx_recorder_create": (C.c_int, [C.POINTER(_P), C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64]),
+    "igx_recorder_capture": (C.c_int, [_P, _P, _P]),
+    "igx_recorder_sync": (C.c_int, [_P]),
+    "igx_recorder_steps": (C.c_int64, [_P]),
+    "igx_recorder_host_data": (_P, [_P]),
+    "igx_recorder_destroy": (C.c_int, [_P]),
+})
 # AMP motion library / HumanoidAMP
 SYMBOLS.update({
     "igx_motion_state": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),

@@ -11,6 +11,10 @@ _TASKS = {
         env=dict(numEnvs=512, envSpacing=4.0, resetDist=3.0, maxEffort=400.0, clipObservations=5.0, clipActions=1.0,
                  enableCameraSensors=False),
         sim=_SIM, task=dict(randomize=False, randomization_params={})),
+    "CartpoleSample": dict(
+        env=dict(numEnvs=512, envSpacing=4.0, resetDist=3.0, maxEffort=400.0, clipObservations=5.0, clipActions=1.0,
+                 enableCameraSensors=False, is_train=True, sample=False, max_frame_length=900, seed=42),
+        sim=_SIM, task=dict(randomize=False, randomization_params={})),
     "Ant": dict(
         env=dict(numEnvs=4096, envSpacing=5, episodeLength=1000, enableDebugVis=False, clipActions=1.0, powerScale=1.0,
                  controlFrequencyInv=1, headingWeight=0.5, upWeight=0.1, actionsCost=0.005, energyCost=0.05,

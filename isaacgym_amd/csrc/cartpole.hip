@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void cartpole_step_kernel(const igx_cartpole_p
     }
     reinterpret_cast<float4 *>(b.obs)[e] = ds;
     const float half_pi = 1.57079637f;  // float32(np.pi / 2)
-    float reward = 1.0f - ds.z * ds.z - 0.01f * fabsf(ds.y) - 0.005f * fabsf(ds.w);
+    float reward;
+    if (p.reward_variant == 1)  // tasks/cartpole_sample.py:322
+        reward = 1.0f - 0.001f * ds.z * ds.z - 0.001f * fabsf(ds.y) - 0.001f * fabsf(ds.w);
+    else
+        reward = 1.0f - ds.z * ds.z - 0.01f * fabsf(ds.y) - 0.005f * fabsf(ds.w);
     const bool out = fabsf(ds.x) > p.reset_dist;
     const bool fell = fabsf(ds.z) > half_pi;
     if (out || fell) {
@@ -98,6 +102,8 @@ extern "C" int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpol
     if (!p || !b) return igx::fail(IGX_E_NULL, "igx_cartpole_step: params/buffers struct is NULL");
     if (n_envs < 0 || n_envs > ((int64_t)1 << 38))
         return igx::fail(IGX_E_SIZE, "igx_cartpole_step: n_envs %lld out of range", (long long)n_envs);
+    if (p->reward_variant < 0 || p->reward_variant > 1)
+        return igx::fail(IGX_E_PARAM, "igx_cartpole_step: unknown reward_variant %d", p->reward_variant);
     if (n_envs == 0) return IGX_OK;  // empty batch: nothing to validate or launch
     IGX_REQUIRE_PTR(b->dof_state, "dof_state");
     IGX_REQUIRE_PTR(b->obs, "obs");

@@ -1,0 +1,151 @@
+// Trajectory recorder: selected columns of a [n_rows, row_width] device buffer,
+// every step, to pinned host memory without stalling the producer.
+//
+//   capture k:  producer stream   wait(slot_free[k % S])            (only when the ring wraps)
+//                                 gather kernel -> staging slot k % S   [num_cols][n_rows]
+//                                 record(slot_full[k % S])
+//               copy stream       wait(slot_full[k % S])
+//                                 hipMemcpyAsync(host + k * slab, slot, D2H)   (pinned, one contiguous slab)
+//                                 record(slot_free[k % S])
+//
+// The producer only ever waits for a copy that is S captures old.  Replaces the
+// per-step obs.clone().cpu() + torch.cat of tasks/cartpole_sample.py:119-121,
+// :289-293 (reference paths relative to IsaacGymEnvs/isaacgymenvs/).
+#include <new>
+#include <vector>
+
+#include "igx_device.hpp"
+#include "igx_host.hpp"
+#include "igx_tile.hpp"
+
+struct igx_recorder {
+    int64_t n_rows = 0, max_steps = 0, steps = 0;
+    int32_t row_width = 0, num_cols = 0, ring_slots = 0;
+    int device = -1;
+    int32_t *d_cols = nullptr;
+    float *d_ring = nullptr;   // [ring_slots][num_cols][n_rows]
+    float *h_data = nullptr;   // [max_steps][num_cols][n_rows], pinned
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> slot_full, slot_free;
+};
+
+namespace igx {
+
+// out[c][row] = src[row][cols[c]]: a wave reads 64 consecutive rows of one column
+// (strided, but the whole tile of rows is touched by the num_cols passes while it is
+// in cache) and writes 256 contiguous bytes
+__global__ __launch_bounds__(256) void recorder_gather_kernel(const float *__restrict__ src, int row_width,
+                                                              const int32_t *__restrict__ cols, int num_cols,
+                                                              int64_t n_rows, float *__restrict__ out)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const float *r = src + row * row_width;
+    for (int c = 0; c < num_cols; ++c) st_stream(out + (int64_t)c * n_rows + row, r[cols[c]]);
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    fail((int)e, "igx_recorder: %s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+}  // namespace igx
+
+using namespace igx;
+
+#define REC_HIP(call, what)                              \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) {                          \
+            igx_recorder_destroy(r);                     \
+            return hip_fail(e_, what);                   \
+        }                                                \
+    } while (0)
+
+extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t row_width, const int32_t *cols,
+                                   int32_t num_cols, int32_t ring_slots, int64_t max_steps)
+{
+    if (!out || !cols) return fail(IGX_E_NULL, "igx_recorder_create: NULL argument");
+    *out = nullptr;
+    if (n_rows <= 0 || row_width <= 0 || num_cols <= 0 || num_cols > 1024 || ring_slots < 1 || ring_slots > 64 ||
+        max_steps <= 0)
+        return fail(IGX_E_SIZE, "igx_recorder_create: bad sizes");
+    for (int c = 0; c < num_cols; ++c)
+        if (cols[c] < 0 || cols[c] >= row_width) return fail(IGX_E_PARAM, "igx_recorder_create: column %d out of range", cols[c]);
+    const int64_t slab = (int64_t)num_cols * n_rows;
+    if (slab > ((int64_t)1 << 40) / max_steps) return fail(IGX_E_SIZE, "igx_recorder_create: host buffer too large");
+    igx_recorder *r = new (std::nothrow) igx_recorder();
+    if (!r) return fail(IGX_E_SIZE, "igx_recorder_create: out of host memory");
+    r->n_rows = n_rows; r->row_width = row_width; r->num_cols = num_cols; r->ring_slots = ring_slots;
+    r->max_steps = max_steps;
+    REC_HIP(hipGetDevice(&r->device), "hipGetDevice");
+    REC_HIP(hipMalloc(&r->d_cols, sizeof(int32_t) * num_cols), "hipMalloc(cols)");
+    REC_HIP(hipMemcpy(r->d_cols, cols, sizeof(int32_t) * num_cols, hipMemcpyHostToDevice), "hipMemcpy(cols)");
+    REC_HIP(hipMalloc(&r->d_ring, sizeof(float) * slab * ring_slots), "hipMalloc(ring)");
+    REC_HIP(hipHostMalloc(&r->h_data, sizeof(float) * slab * max_steps, hipHostMallocDefault), "hipHostMalloc");
+    REC_HIP(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (int s = 0; s < ring_slots; ++s) {
+        hipEvent_t a = nullptr, b = nullptr;
+        REC_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming), "hipEventCreate");
+        r->slot_full.push_back(a);
+        REC_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming), "hipEventCreate");
+        r->slot_free.push_back(b);
+    }
+    *out = r;
+    return IGX_OK;
+}
+
+#undef REC_HIP
+#define REC_HIP(call, what)                              \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return hip_fail(e_, what); \
+    } while (0)
+
+extern "C" int igx_recorder_capture(igx_recorder *r, const float *src, igx_stream_t producer_stream)
+{
+    if (!r || !src) return fail(IGX_E_NULL, "igx_recorder_capture: NULL argument");
+    if (r->steps >= r->max_steps) return fail(IGX_E_SIZE, "igx_recorder_capture: all %lld steps taken", (long long)r->max_steps);
+    hipStream_t ps = static_cast<hipStream_t>(producer_stream);
+    const int slot = (int)(r->steps % r->ring_slots);
+    const int64_t slab = (int64_t)r->num_cols * r->n_rows;
+    float *stage = r->d_ring + slab * slot;
+    if (r->steps >= r->ring_slots) REC_HIP(hipStreamWaitEvent(ps, r->slot_free[slot], 0), "wait(slot_free)");
+    hipLaunchKernelGGL(recorder_gather_kernel, dim3((unsigned)((r->n_rows + 255) / 256)), dim3(256), 0, ps, src,
+                       (int)r->row_width, r->d_cols, (int)r->num_cols, r->n_rows, stage);
+    int rc = launch_status("igx_recorder_capture");
+    if (rc != IGX_OK) return rc;
+    REC_HIP(hipEventRecord(r->slot_full[slot], ps), "record(slot_full)");
+    REC_HIP(hipStreamWaitEvent(r->copy_stream, r->slot_full[slot], 0), "wait(slot_full)");
+    REC_HIP(hipMemcpyAsync(r->h_data + slab * r->steps, stage, sizeof(float) * slab, hipMemcpyDeviceToHost, r->copy_stream),
+            "hipMemcpyAsync");
+    REC_HIP(hipEventRecord(r->slot_free[slot], r->copy_stream), "record(slot_free)");
+    r->steps += 1;
+    return IGX_OK;
+}
+
+extern "C" int igx_recorder_sync(igx_recorder *r)
+{
+    if (!r) return fail(IGX_E_NULL, "igx_recorder_sync: NULL recorder");
+    REC_HIP(hipStreamSynchronize(r->copy_stream), "hipStreamSynchronize");
+    return IGX_OK;
+}
+
+extern "C" int64_t igx_recorder_steps(const igx_recorder *r) { return r ? r->steps : -1; }
+
+extern "C" const float *igx_recorder_host_data(const igx_recorder *r) { return r ? r->h_data : nullptr; }
+
+extern "C" int igx_recorder_destroy(igx_recorder *r)
+{
+    if (!r) return IGX_OK;
+    if (r->copy_stream) (void)hipStreamSynchronize(r->copy_stream);
+    for (hipEvent_t e : r->slot_full) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->slot_free) (void)hipEventDestroy(e);
+    if (r->copy_stream) (void)hipStreamDestroy(r->copy_stream);
+    if (r->d_cols) (void)hipFree(r->d_cols);
+    if (r->d_ring) (void)hipFree(r->d_ring);
+    if (r->h_data) (void)hipHostFree(r->h_data);
+    delete r;
+    return IGX_OK;
+}

@@ -53,6 +53,7 @@ class TensorSim:
 
 _PHYSICS_OWNED = {
     "Cartpole": ("dof_state",),
+    "CartpoleSample": ("dof_state",),
     "Ant": ("root_states", "dof_state", "sensors"),
     "Humanoid": ("root_states", "dof_state", "sensors", "dof_force"),
     "AllegroHand": ("dof_state", "dof_force", "root_state_tensor"),
@@ -61,7 +62,7 @@ _PHYSICS_OWNED = {
 
 
 def _draw(task, n, seed, device, **kw):
-    if task == "Cartpole":
+    if task in ("Cartpole", "CartpoleSample"):
         return synthetic.cartpole_state(n, seed, device)
     if task == "Ant":
         return synthetic.loco_state(synthetic.ANT, n, seed, device)

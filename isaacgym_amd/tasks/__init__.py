@@ -2,6 +2,7 @@
 from .allegro_hand import AllegroHand
 from .ant import Ant
 from .cartpole import Cartpole
+from .cartpole_sample import CartpoleSample
 from .humanoid import Humanoid
 from .humanoid_amp import HumanoidAMP
 
@@ -9,6 +10,7 @@ isaacgym_task_map = {
     "AllegroHand": AllegroHand,
     "Ant": Ant,
     "Cartpole": Cartpole,
+    "CartpoleSample": CartpoleSample,
     "Humanoid": Humanoid,
     "HumanoidAMP": HumanoidAMP,
 }

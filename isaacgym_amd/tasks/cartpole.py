@@ -9,6 +9,8 @@ from .base.vec_task import VecTask
 
 
 class Cartpole(VecTask):
+    REWARD_VARIANT = 0
+
     def __init__(self, cfg, rl_device, sim_device, graphics_device_id=0, headless=True, virtual_screen_capture=False,
                  force_render=False, sim=None, seed=0):
         self.cfg = cfg
@@ -31,7 +33,7 @@ class Cartpole(VecTask):
     def _params(self):
         self._draws += 1
         return _abi.CartpoleParams(reset_dist=self.reset_dist, max_episode_length_m1=float(self.max_episode_length - 1),
-                                   seed=self.seed, rng_offset=self._draws)
+                                   reward_variant=self.REWARD_VARIANT, seed=self.seed, rng_offset=self._draws)
 
     def _buffers(self):
         return dict(dof_state=self.dof_state, rand=self.reset_rand, obs=self.obs_buf, rew=self.rew_buf,

@@ -137,6 +137,79 @@ def gen_cartpole(seed=0, N=4096, T=4):
     print("cartpole.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+def gen_cartpole_sample(seed=5, N=257, T=6):
+    """CartpoleSample (tasks/cartpole_sample.py): the fork's trajectory-sampling variant.
+    Records its post_physics_step (reward variant :316-335) and the sequence dict that
+    sample mode accumulates (:99-107, :289-293)."""
+    from collections import defaultdict
+    _install_gym_stubs()
+    mod = ref_shim.load("isaacgymenvs.tasks.cartpole_sample")
+    cfg = _cfg("CartpoleSample") if os.path.exists(os.path.join(CFG, "CartpoleSample.yaml")) else _cfg("Cartpole")
+
+    class Fake(mod.CartpoleSample):
+        def __init__(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    t = Fake()
+    t.cfg = cfg
+    t.reset_dist = cfg["env"]["resetDist"]
+    t.max_episode_length = 500
+    t.num_envs, t.num_dof, t.device = N, 2, "cpu"
+    t.gym, t.sim = _Any(), None
+    t.sample, t.is_train, t.frame_no, t.max_frame_length = True, True, 0, 900
+    t.dof_state = torch.zeros(N * 2, 2)
+    t.dof_pos = t.dof_state.view(N, 2, 2)[..., 0]
+    t.dof_vel = t.dof_state.view(N, 2, 2)[..., 1]
+    t.obs_buf = torch.zeros(N, 4)
+    t.rew_buf = torch.zeros(N)
+    t.reset_buf = torch.zeros(N, dtype=torch.long)
+    t.progress_buf = torch.randint(0, 500, (N,), generator=g)
+    t.progress_buf[:4] = torch.tensor([497, 498, 499, 0])
+
+    def draw():
+        ds = torch.empty(N, 2, 2)
+        ds[:, 0, 0] = (torch.rand(N, generator=g) * 2 - 1) * 3.5
+        ds[:, 1, 0] = (torch.rand(N, generator=g) * 2 - 1) * 2.0
+        ds[:, :, 1] = torch.randn(N, 2, generator=g)
+        return ds
+
+    ds0 = draw()
+    t.dof_state.copy_(ds0.view(N * 2, 2))
+    t.sequence = defaultdict()
+    t.sequence["x"], t.sequence["theta"] = t.get_x_theta(t.compute_observations())
+    rec = {k: [] for k in ("in_dof_state", "rand", "out_dof_state", "obs", "rew", "reset", "progress")}
+    init = {"reset0": t.reset_buf.numpy().copy(), "progress0": t.progress_buf.numpy().copy(),
+            "dof_state0": ds0.numpy().reshape(N * 2, 2).copy()}
+    torch.manual_seed(seed + 100)
+    for step in range(T):
+        t.dof_state.copy_(draw().view(N * 2, 2))
+        rec["in_dof_state"].append(t.dof_state.numpy().copy())
+        ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        st = torch.get_rng_state()
+        t.post_physics_step()
+        dense = np.zeros((N, 4), np.float32)
+        if len(ids) > 0:
+            up, uv = _replay_uniforms(st, [(len(ids), 2), (len(ids), 2)])
+            dense[ids.numpy(), 0:2] = up.numpy()
+            dense[ids.numpy(), 2:4] = uv.numpy()
+        rec["rand"].append(dense)
+        rec["out_dof_state"].append(t.dof_state.numpy().copy())
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(init)
+    out["sequence_x"] = t.sequence["x"].numpy().copy()          # [N, T+1]
+    out["sequence_theta"] = t.sequence["theta"].numpy().copy()
+    out["meta"] = _meta(task="CartpoleSample", N=N, T=T, seed=seed, reset_dist=t.reset_dist,
+                        max_episode_length=t.max_episode_length)
+    np.savez_compressed(os.path.join(OUT, "cartpole_sample.npz"), **out)
+    print("cartpole_sample.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+          "resets", int(out["reset"].sum()))
+
+
 # --------------------------------------------------------------------------
 def _loco_common(t, cfg, N, D, g, z_mean):
     e = cfg["env"]
@@ -913,7 +986,7 @@ def gen_vectask(seed=21, N=301, T=3):
     print("vectask.npz", {k: (v.shape, v.dtype) for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"vectask": gen_vectask, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -251,7 +251,11 @@ int orc_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *
         float cart_pos = ds[0], cart_vel = ds[1], pole_angle = ds[2], pole_vel = ds[3];
         float *o = b->obs + e * 4;
         o[0] = cart_pos; o[1] = cart_vel; o[2] = pole_angle; o[3] = pole_vel;
-        float reward = 1.0f - pole_angle * pole_angle - 0.01f * fabsf(cart_vel) - 0.005f * fabsf(pole_vel);
+        float reward;
+        if (p->reward_variant == 1) /* tasks/cartpole_sample.py:322 */
+            reward = 1.0f - 0.001f * pole_angle * pole_angle - 0.001f * fabsf(cart_vel) - 0.001f * fabsf(pole_vel);
+        else
+            reward = 1.0f - pole_angle * pole_angle - 0.01f * fabsf(cart_vel) - 0.005f * fabsf(pole_vel);
         if (fabsf(cart_pos) > p->reset_dist) reward = -2.0f;
         if (fabsf(pole_angle) > half_pi) reward = -2.0f;
         if (fabsf(cart_pos) > p->reset_dist) rst = 1;

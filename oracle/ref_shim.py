@@ -59,7 +59,7 @@ def install():
             return _Any()
 
     for name in ("isaacgym", "isaacgym.gymtorch", "isaacgym.gymapi", "isaacgym.gymutil",
-                 "imageio", "gym", "gym.spaces"):
+                 "imageio", "cv2", "gym", "gym.spaces"):
         _stub(name)
     sys.modules["isaacgym"].gymtorch = sys.modules["isaacgym.gymtorch"]
     sys.modules["isaacgym"].gymapi = sys.modules["isaacgym.gymapi"]

@@ -64,6 +64,7 @@ def bit_equal_fraction(x, ref):
 def cartpole_params(meta, seed=0, rng_offset=0):
     return _abi.CartpoleParams(reset_dist=meta["reset_dist"],
                                max_episode_length_m1=float(meta["max_episode_length"] - 1),
+                               reward_variant=1 if meta["task"] == "CartpoleSample" else 0,
                                seed=seed, rng_offset=rng_offset)
 
 

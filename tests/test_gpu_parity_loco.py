@@ -16,8 +16,9 @@ def _to_dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def test_cartpole_golden():
-    g = H.load_golden("cartpole")
+@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample"])
+def test_cartpole_golden(name):
+    g = H.load_golden(name)
     m = g["meta"]
     N, T = m["N"], m["T"]
     p = H.cartpole_params(m)

@@ -7,8 +7,12 @@ from oracle import oracle
 from tests import helpers as H
 
 
-def test_cartpole_oracle_matches_reference():
-    g = H.load_golden("cartpole")
+import pytest
+
+
+@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample"])
+def test_cartpole_oracle_matches_reference(name):
+    g = H.load_golden(name)
     m = g["meta"]
     N, T = m["N"], m["T"]
     p = H.cartpole_params(m)
