@@ -55,10 +55,10 @@ __device__ __forceinline__ void load_chunks(const float *__restrict__ g, v4f (&v
 }
 
 // Rows of ROW floats -> columns C0.. of the LDS observation rows (optionally scaled).
-template <int ROW, int C0, int NOBS, bool SCALE, int ITERS>
+template <int ROW, int C0, int NOBS, bool SCALE, int T = WAVE, int ITERS = 1>
 __device__ __forceinline__ void stage_rows(const v4f (&v)[ITERS], float *s_tile, float scl, int lane)
 {
-    constexpr int N4 = WAVE * ROW / 4;
+    constexpr int N4 = T * ROW / 4;  // T rows per tile, WAVE lanes
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int k = lane + it * WAVE;
@@ -84,11 +84,11 @@ __device__ __forceinline__ void stage_rows(const v4f (&v)[ITERS], float *s_tile,
 
 // Interleaved (pos, vel) rows: position -> unscale -> column C_POS+j,
 // velocity * dof_vel_scale -> column C_VEL+j.
-template <int D, int NOBS, int C_POS, int C_VEL, int ITERS>
+template <int D, int NOBS, int C_POS, int C_VEL, int T = WAVE, int ITERS = 1>
 __device__ __forceinline__ void stage_dof_state(const v4f (&v)[ITERS], float *s_tile, const float *s_lim,
                                                 float dof_vel_scale, int lane)
 {
-    constexpr int N4 = WAVE * D * 2 / 4;
+    constexpr int N4 = T * D * 2 / 4;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int k = lane + it * WAVE;
