@@ -479,26 +479,27 @@ extern "C" int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_al
 static int allegro_post_launch(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, igx_stream_t stream)
 {
     int rc;
+    static const int reserve = tuning_int("IGX_ALLEGRO_LDS_RESERVE", 0);  // unused LDS: caps the waves per CU
     const unsigned tiles = (unsigned)((n + WAVE - 1) / WAVE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->obs_type) {
     case IGX_ALLEGRO_OBS_FULL_NO_VEL:
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_NO_VEL, true>), dim3(tiles), dim3(WAVE), 0, s, *p, *b,
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_NO_VEL, true>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b,
                            b->obs, n);
         break;
     case IGX_ALLEGRO_OBS_FULL:
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL, true>), dim3(tiles), dim3(WAVE), 0, s, *p, *b,
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL, true>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b,
                            b->obs, n);
         break;
     default:
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, true>), dim3(tiles), dim3(WAVE), 0, s, *p, *b,
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, true>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b,
                            b->obs, n);
         break;
     }
     rc = launch_status("igx_allegro_post_physics");
     if (rc != IGX_OK) return rc;
     if (b->states && p->obs_type != IGX_ALLEGRO_OBS_FULL_STATE) {  // asymmetric critic state beside a smaller policy obs
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, false>), dim3(tiles), dim3(WAVE), 0, s, *p,
+        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, false>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p,
                            *b, b->states, n);
         rc = launch_status("igx_allegro_post_physics(states)");
         if (rc != IGX_OK) return rc;

@@ -615,11 +615,12 @@ extern "C" int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buff
     if (!b->contact_forces || !b->rew) return fail(IGX_E_NULL, "igx_humanoid_amp_step: contact_forces / rew is NULL");
     const dim3 grid((unsigned)((n + WAVE - 1) / WAVE));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int reserve = tuning_int("IGX_AMP_LDS_RESERVE", 0);  // unused LDS: caps the waves per CU
     switch (p->num_amp_obs_steps) {
-    case 2: hipLaunchKernelGGL(amp_step_kernel<2>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
-    case 3: hipLaunchKernelGGL(amp_step_kernel<3>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
-    case 4: hipLaunchKernelGGL(amp_step_kernel<4>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
-    default: hipLaunchKernelGGL(amp_step_kernel<0>, grid, dim3(WAVE), 0, s, *p, *b, n); break;
+    case 2: hipLaunchKernelGGL(amp_step_kernel<2>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    case 3: hipLaunchKernelGGL(amp_step_kernel<3>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    case 4: hipLaunchKernelGGL(amp_step_kernel<4>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    default: hipLaunchKernelGGL(amp_step_kernel<0>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
     }
     return launch_status("igx_humanoid_amp_step");
 }

@@ -1,5 +1,6 @@
 // Library identification and per-thread error reporting of libigx.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "igx_host.hpp"
@@ -29,6 +30,15 @@ int launch_status(const char *what)
         return (int)e;
     }
     return IGX_OK;
+}
+
+int tuning_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    return (end && *end == '\0') ? (int)x : dflt;
 }
 
 }  // namespace igx

@@ -18,6 +18,9 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // return convention (0 or the positive hipError_t) without synchronising.
 int launch_status(const char *what);
 
+// Integer launch-tuning knob: environment variable `name` if set, else `dflt`.
+int tuning_int(const char *name, int dflt);
+
 }  // namespace igx
 
 #define IGX_REQUIRE_PTR(ptr, name)                                              \

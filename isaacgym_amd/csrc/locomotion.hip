@@ -37,12 +37,10 @@ namespace igx {
 // (5 waves per CU); with 32-row tiles the upper half of the wave idles during the
 // per-environment math, which is hidden behind memory anyway, and twice as many waves
 // stream (measured 199 -> 189 us per 2^20 envs).  Ant is insensitive (106 us either way).
-template <bool HUM>
-constexpr int tile_rows() { return HUM ? 32 : 64; }
-
-template <int D, int S, bool HUM>
+template <int D, int S, bool HUM, int T>
 struct LocoLayout {
-    static constexpr int TILE = tile_rows<HUM>();
+    static constexpr int TILE = T;
+    static_assert(T == 32 || T == 64, "tile rows");
     static constexpr int C_POS = 12;
     static constexpr int C_VEL = 12 + D;
     static constexpr int C_FORCE = 12 + 2 * D;  // Humanoid only
@@ -64,11 +62,11 @@ struct LocoLayout {
 // environment at a time with the wave's lanes spread over the joints: lane j
 // draws joint j's position and velocity uniforms, writes the (pos, vel) pair
 // to dof_state and the two derived observation columns to the LDS row.
-template <int D, int S, bool HUM>
+template <int D, int S, bool HUM, int T>
 __device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx_loco_buffers &b, int64_t base,
                                              int lane, uint64_t reset_mask, float *s_tile, const float *s_lim)
 {
-    using L = LocoLayout<D, S, HUM>;
+    using L = LocoLayout<D, S, HUM, T>;
     while (reset_mask) {
         const int src = __builtin_ctzll(reset_mask);
         reset_mask &= reset_mask - 1;
@@ -102,12 +100,12 @@ __device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx
 
 // What lane i computes for environment e from its root row (13 registers) and
 // its LDS observation row.  Returns up_vec / heading_vec for the drain.
-template <int D, int S, bool HUM>
+template <int D, int S, bool HUM, int T>
 __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco_buffers &b, int64_t e,
                                         const float (&rr)[13], int64_t prog, int64_t rst, int64_t rnd, float pot,
                                         float *row, const float *s_lim, f3 &up_vec, f3 &heading_vec)
 {
-    using L = LocoLayout<D, S, HUM>;
+    using L = LocoLayout<D, S, HUM, T>;
     constexpr int NOBS = L::NOBS;
     const f3 pos{rr[0], rr[1], rr[2]};
     const f4 rot{rr[3], rr[4], rr[5], rr[6]};
@@ -207,28 +205,28 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
 #endif
 
 // Everything a tile reads, as it sits in registers after the load phase.
-template <int D, int S, bool HUM>
+template <int D, int S, bool HUM, int T>
 struct TileIn {
-    using L = LocoLayout<D, S, HUM>;
+    using L = LocoLayout<D, S, HUM, T>;
     int64_t prog, rst, rnd;
     float pot;
     v4f r_root[L::IT_ROOT], r_dof[L::IT_DOF], r_sens[L::IT_SENS], r_act[L::IT_ACT], r_force[HUM ? L::IT_ACT : 1];
 };
 
-template <int D, int S, bool HUM>
-__device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t base, int64_t n, int lane, TileIn<D, S, HUM> &t)
+template <int D, int S, bool HUM, int T>
+__device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t base, int64_t n, int lane, TileIn<D, S, HUM, T> &t)
 {
-    using L = LocoLayout<D, S, HUM>;
+    using L = LocoLayout<D, S, HUM, T>;
     constexpr int TILE = L::TILE;
     const int nvalid = (n - base >= TILE) ? TILE : (int)(n - base);
-    const int64_t e = base + lane;
-    t.prog = 0; t.rst = 0; t.rnd = 0; t.pot = 0.0f;
-    if (lane < nvalid) {
-        t.prog = ld_stream(b.progress + e);
-        t.rst = ld_stream(b.reset + e);
-        t.pot = ld_stream(b.potentials + e);
-        if (b.randomize) t.rnd = ld_stream(b.randomize + e);
-    }
+    // branch-free so that every load of the tile is issued before the first wait: lanes
+    // without an environment re-read the tile's first one, a missing randomize buffer
+    // re-reads progress (both results are never used)
+    const int64_t e = base + (lane < nvalid ? lane : 0);
+    t.prog = ld_stream(b.progress + e);
+    t.rst = ld_stream(b.reset + e);
+    t.pot = ld_stream(b.potentials + e);
+    t.rnd = ld_stream((b.randomize ? b.randomize : b.progress) + e);
     if (nvalid == TILE) {
         load_chunks<L::ROOT4>(b.root_states + base * 13, t.r_root, lane);
         load_chunks<L::DOF4>(b.dof_state + base * (2 * D), t.r_dof, lane);
@@ -238,10 +236,10 @@ __device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t bas
     }
 }
 
-template <int D, int S, bool HUM>
+template <int D, int S, bool HUM, int T>
 __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p, const igx_loco_buffers b, int64_t n)
 {
-    using L = LocoLayout<D, S, HUM>;
+    using L = LocoLayout<D, S, HUM, T>;
     constexpr int NOBS = L::NOBS;
     constexpr int TILE = L::TILE;
     static_assert(NOBS % 4 == 0, "observation rows must be a multiple of 16 bytes");
@@ -252,12 +250,23 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
     const int lane = threadIdx.x;
     const int64_t base0 = (int64_t)blockIdx.x * (TILE * IGX_LOCO_TPW);
 
-    if (lane < 2 * D) s_lim[lane] = (lane < D) ? p.dof_limits_lower[lane] : p.dof_limits_upper[lane - D];
-    if (HUM && lane < D) s_lim[2 * D + lane] = p.motor_efforts[lane] / p.max_motor_effort;
+    // per-dof constants picked out of the (scalar) kernel arguments by a select chain: a
+    // lane-indexed read of the argument block would be a vector memory load that the
+    // tile's streaming loads then have to queue behind
+    float lim = 0.0f, effort = 1.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        lim = lane == j ? p.dof_limits_lower[j] : lim;
+        lim = lane == D + j ? p.dof_limits_upper[j] : lim;
+        if (HUM) effort = lane == j ? p.motor_efforts[j] : effort;
+    }
 
     // ---- load: everything the first tile reads, issued back to back
-    TileIn<D, S, HUM> in;
-    load_tile<D, S, HUM>(b, base0, n, lane, in);
+    TileIn<D, S, HUM, T> in;
+    load_tile<D, S, HUM, T>(b, base0, n, lane, in);
+
+    if (lane < 2 * D) s_lim[lane] = lim;
+    if (HUM && lane < D) s_lim[2 * D + lane] = effort / p.max_motor_effort;
 
 #pragma unroll
     for (int tpw = 0; tpw < IGX_LOCO_TPW; ++tpw) {
@@ -307,19 +316,19 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
             }
         }
         // the load registers are free again: the next tile's inputs travel while this one is computed
-        if (tpw + 1 < IGX_LOCO_TPW && base + TILE < n) load_tile<D, S, HUM>(b, base + TILE, n, lane, in);
+        if (tpw + 1 < IGX_LOCO_TPW && base + TILE < n) load_tile<D, S, HUM, T>(b, base + TILE, n, lane, in);
         wave_sync();
 
         // ---- reset: re-draw the joints of flagged environments (rare)
         const uint64_t reset_mask = __ballot(live && rst != 0);
         if (reset_mask) {
-            reset_joints<D, S, HUM>(p, b, base, lane, reset_mask, s_tile, s_lim);
+            reset_joints<D, S, HUM, T>(p, b, base, lane, reset_mask, s_tile, s_lim);
             wave_sync();
         }
 
         // ---- per-env math
         f3 up_vec{0, 0, 0}, heading_vec{0, 0, 0};
-        if (live) per_env<D, S, HUM>(p, b, e, rr, prog, rst, rnd, pot, s_tile + lane * NOBS, s_lim, up_vec, heading_vec);
+        if (live) per_env<D, S, HUM, T>(p, b, e, rr, prog, rst, rnd, pot, s_tile + lane * NOBS, s_lim, up_vec, heading_vec);
         wave_sync();
 
         // ---- drain: finished rows out as whole lines
@@ -444,18 +453,34 @@ static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64
     return IGX_OK;
 }
 
+template <int D, int S, bool HUM, int T>
+static int launch_loco_tile(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int lds_reserve,
+                            igx_stream_t stream, const char *who)
+{
+    const int64_t tiles = (n + T - 1) / T;
+    if (tiles > 0x7fffffffLL) return fail(IGX_E_SIZE, "%s: n_envs too large for one launch", who);
+    const int64_t blocks = (tiles + IGX_LOCO_TPW - 1) / IGX_LOCO_TPW;
+    hipLaunchKernelGGL((loco_step_kernel<D, S, HUM, T>), dim3((unsigned)blocks), dim3(WAVE), (size_t)lds_reserve,
+                       static_cast<hipStream_t>(stream), *p, *b, n);
+    return launch_status(who);
+}
+
+// Launch shape.  Two measured knobs per task (2^20 envs, MI355X): the rows per tile and a
+// reservation of unused LDS that caps the resident waves per CU - this multi-array streaming
+// pattern runs fastest with FEWER waves in flight than the LDS tile alone would allow
+// (Ant: 10 waves/CU 107.4 us, 6 waves 104.5 us, 5 waves 102.7 us, 3 waves 111 us; Humanoid is
+// fastest with 32-row tiles and no reservation).
+// IGX_{ANT,HUMANOID}_TILE / _LDS_RESERVE override the defaults for tuning runs.
 template <int D, int S, bool HUM>
 static int launch_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, igx_stream_t stream,
                        const char *who)
 {
     if (n == 0) return IGX_OK;
-    constexpr int TILE = tile_rows<HUM>();
-    const int64_t tiles = (n + TILE - 1) / TILE;
-    if (tiles > 0x7fffffffLL) return fail(IGX_E_SIZE, "%s: n_envs too large for one launch", who);
-    const int64_t blocks = (tiles + IGX_LOCO_TPW - 1) / IGX_LOCO_TPW;
-    hipLaunchKernelGGL((loco_step_kernel<D, S, HUM>), dim3((unsigned)blocks), dim3(WAVE), 0,
-                       static_cast<hipStream_t>(stream), *p, *b, n);
-    return launch_status(who);
+    static const int tile = tuning_int(HUM ? "IGX_HUMANOID_TILE" : "IGX_ANT_TILE", HUM ? 32 : 64);
+    static const int reserve = tuning_int(HUM ? "IGX_HUMANOID_LDS_RESERVE" : "IGX_ANT_LDS_RESERVE", HUM ? 0 : 13000);
+    if (reserve < 0 || reserve > 120 * 1024) return fail(IGX_E_PARAM, "%s: LDS reservation %d out of range", who, reserve);
+    if (tile == 32) return launch_loco_tile<D, S, HUM, 32>(p, b, n, reserve, stream, who);
+    return launch_loco_tile<D, S, HUM, 64>(p, b, n, reserve, stream, who);
 }
 
 }  // namespace igx
