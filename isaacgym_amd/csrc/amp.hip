@@ -8,13 +8,14 @@
 //                        every lane writes its own observation columns, the
 //                        interpolated state never touches memory.
 //  igx_amp_observations  build_amp_observations on given state arrays.
-//  igx_humanoid_amp_step post_physics_step: a wavefront owns 64 environments;
-//                        root rows and the dof_state slab stream in through
-//                        LDS, lane i computes environment i's 105 observation
-//                        columns into the LDS tile, contact forces stream
-//                        through a predicate, body heights / key-body positions
-//                        are gathered per lane; the observation rows and the
-//                        shifted AMP history leave as whole contiguous lines.
+//  igx_humanoid_amp_step post_physics_step: a wavefront owns 32 environments,
+//                        two lanes each.  Rigid-body rows, contact forces, root
+//                        rows and the dof_state slab are streamed coalesced and
+//                        transposed through the (still empty) observation tile
+//                        in phases; the lane pair splits the 12 joints; the
+//                        observation rows leave as whole contiguous lines and
+//                        the AMP history is shifted with 16-byte loads at
+//                        4-byte-aligned addresses.
 //  igx_humanoid_amp_reset reset_idx: scatter of sampled reference states and
 //                        recomputation of the touched rows (one lane per env).
 //
@@ -267,41 +268,6 @@ __device__ __forceinline__ void env_obs_from_global(const igx_amp_params &p, con
     amp_obs_full(load_v(r), load_q(r + 3), load_v(r + 7), load_v(r + 10), ds, ds + 1, 2, key, p.local_root_obs != 0, obs);
 }
 
-// Observation of one environment assembled in place in its LDS row: on entry the row
-// holds the joint velocities at their final columns [65,93) and the joint positions
-// parked at [37,65); joint j's 1 or 6 columns at 13 + DOF_OBS_OFFSETS[j] never reach the
-// position of a joint that is still to be read (DOF_OBS_OFFSETS[j+1] - DOF_OFFSETS[j+1] <= 24).
-constexpr int POS_PARK = 37;
-__device__ __forceinline__ void amp_obs_inplace(const float (&rr)[13], const float *key, bool local_root_obs, float *row)
-{
-    const f3 root_pos{rr[0], rr[1], rr[2]};
-    f4 heading_rot;
-    float c[13];
-    root_obs(root_pos, f4{rr[3], rr[4], rr[5], rr[6]}, f3{rr[7], rr[8], rr[9]}, f3{rr[10], rr[11], rr[12]},
-             local_root_obs, heading_rot, c);
-#pragma unroll
-    for (int i = 0; i < 13; ++i) row[i] = c[i];
-#pragma unroll 1
-    for (int j = 0; j < 12; ++j) {
-        const int off = DOF_OFFSETS[j], size = DOF_OFFSETS[j + 1] - off;
-        float d[3] = {row[POS_PARK + off], 0.0f, 0.0f}, o6[6];
-        if (size == 3) {
-            d[1] = row[POS_PARK + off + 1];
-            d[2] = row[POS_PARK + off + 2];
-        }
-        joint_obs(d, size, o6);
-        float *dst = row + 13 + DOF_OBS_OFFSETS[j];
-        dst[0] = o6[0];
-        if (size == 3) { dst[1] = o6[1]; dst[2] = o6[2]; dst[3] = o6[3]; dst[4] = o6[4]; dst[5] = o6[5]; }
-    }
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const f3 l = quat_rotate<false>(heading_rot, f3{key[3 * k] - root_pos.x, key[3 * k + 1] - root_pos.y,
-                                                        key[3 * k + 2] - root_pos.z});
-        row[93 + 3 * k] = l.x; row[94 + 3 * k] = l.y; row[95 + 3 * k] = l.z;
-    }
-}
-
 // AMP history of a group of G environments (rows of KK * 105 floats, newest first):
 // every slot moves one place back, slot 0 takes the new observation from the LDS tile.
 // All of the group's source chunks are in registers before its first store; a row is
@@ -353,140 +319,205 @@ __device__ __forceinline__ void shift_history(float *__restrict__ amp, const flo
     }
 }
 
-// KK = compile-time number of history steps (0: any, slower path)
+// KK below = compile-time number of history steps (0: any, slower path)
+
+// ---- 32-row tiles, two lanes per environment ---------------------------------------------
+// Lane l and lane l + 32 share environment l of the tile: the lower lane computes the root
+// columns and joints {0,1,2,4 | 3,5}, the upper lane joints {6,8,9,11 | 7,10} and the key-body
+// columns, so both lanes meet a 3-dof joint (or a hinge) in the same loop iteration.  Half the
+// LDS per wave and half the per-environment latency of the one-lane-per-row kernel above.
+constexpr int PAIR_T = 32;
+constexpr int POS_STRIDE = ND + 1;  // odd stride: conflict-free row reads
+__device__ constexpr int PAIR_DOF_OFF[2][6] = {{0, 3, 6, 10, 9, 13}, {14, 18, 21, 25, 17, 24}};
+__device__ constexpr int PAIR_OBS_OFF[2][6] = {{0, 6, 12, 19, 18, 25}, {26, 33, 39, 46, 32, 45}};
+
 template <int KK>
-__global__ __launch_bounds__(WAVE) void amp_step_kernel(const igx_amp_params p, const igx_amp_buffers b, int64_t n)
+__global__ __launch_bounds__(WAVE) void amp_step_pair_kernel(const igx_amp_params p, const igx_amp_buffers b, int64_t n)
 {
-    constexpr int BODY_ROW = NB * 13;  // 195 floats per environment
-    constexpr int HALF = WAVE / 2;
-    __shared__ __align__(16) float s_tile[WAVE * NO];  // transposition scratch first, then the observation rows
-    __shared__ float s_key[WAVE * NK * 3];
-    __shared__ unsigned s_low[WAVE];
-    static_assert(HALF * BODY_ROW <= WAVE * NO, "half a tile of rigid-body rows fits the tile");
-    static_assert(WAVE * (NB * 3 + 13) <= WAVE * NO, "contact + root rows fit the tile");
+    constexpr int T = PAIR_T;
+    constexpr int BODY_ROW = NB * 13;
+    constexpr int Q = T / 2;  // rigid-body rows per phase
+    __shared__ __align__(16) float s_tile[T * NO];
+    __shared__ float s_pos[T * POS_STRIDE];
+    __shared__ float s_key[T * NK * 3];
+    __shared__ unsigned s_flag[T];  // bit 0: a body below the termination height, bit 1: a contact force
+    static_assert(Q * BODY_ROW <= T * NO, "half a tile of rigid-body rows fits the tile");
+    static_assert(T * (NB * 3 + 13) <= T * NO, "contact + root rows fit the tile");
     const int lane = threadIdx.x;
+    const int el = lane & (T - 1), part = lane >> 5;
     const int K = KK ? KK : p.num_amp_obs_steps;
-    const int64_t base = (int64_t)blockIdx.x * WAVE;
-    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
-    const bool full = nvalid == WAVE;
-    const bool live = lane < nvalid;
-    const int64_t e = base + lane;
+    const int64_t base = (int64_t)blockIdx.x * T;
+    const int nvalid = (n - base >= T) ? T : (int)(n - base);
+    const bool full = nvalid == T;
+    const bool live = el < nvalid;
+    const int64_t e = base + (live ? el : 0);
 
-    int64_t prog = 0;
-    if (live) prog = ld_stream(b.progress + e);
-    s_low[lane] = 0;
+    int64_t prog = ld_stream(b.progress + e);
+    if (lane < T) s_flag[lane] = 0;
 
-    // ---- rigid-body rows, half a tile at a time: coalesced into LDS, then lane (env, part)
-    // picks the body heights of its 8 / 7 bodies and two of the key-body positions
-    constexpr int HB4 = HALF * BODY_ROW / 4;  // 1560 chunks
-    v4f r_body[2][(HB4 + WAVE - 1) / WAVE];
+    constexpr int B4 = Q * BODY_ROW / 4, CF4 = T * NB * 3 / 4, ROOT4 = T * 13 / 4, DOF4 = T * 2 * ND / 4;
+    v4f r_body[2][(B4 + WAVE - 1) / WAVE], r_cf[(CF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE],
+        r_dof[DOF4 / WAVE];
     if (full) {
-        load_chunks<HB4>(b.rigid_body_state + base * BODY_ROW, r_body[0], lane);
-        load_chunks<HB4>(b.rigid_body_state + (base + HALF) * BODY_ROW, r_body[1], lane);
+        load_chunks<B4>(b.rigid_body_state + base * BODY_ROW, r_body[0], lane);
+        load_chunks<B4>(b.rigid_body_state + (base + Q) * BODY_ROW, r_body[1], lane);
     }
-    constexpr int CF4 = WAVE * NB * 3 / 4, ROOT4 = WAVE * 13 / 4, DOF4 = WAVE * 2 * ND / 4;
-    v4f r_cf[(CF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE], r_dof[DOF4 / WAVE];
+    // ---- rigid-body rows, 16 environments at a time: lane (row, quarter) takes 4 / 3 body heights
+    // and one key-body position
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int cnt = nvalid - h * HALF < 0 ? 0 : (nvalid - h * HALF > HALF ? HALF : nvalid - h * HALF);
+        const int cnt = nvalid - h * Q < 0 ? 0 : (nvalid - h * Q > Q ? Q : nvalid - h * Q);
         if (full) {
 #pragma unroll
-            for (int it = 0; it < (HB4 + WAVE - 1) / WAVE; ++it) {
+            for (int it = 0; it < (B4 + WAVE - 1) / WAVE; ++it) {
                 const int k = lane + it * WAVE;
-                if ((it + 1) * WAVE <= HB4 || k < HB4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_body[h][it];
+                if ((it + 1) * WAVE <= B4 || k < B4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_body[h][it];
             }
         } else {
-            for (int i = lane; i < cnt * BODY_ROW; i += WAVE) s_tile[i] = b.rigid_body_state[(base + h * HALF) * BODY_ROW + i];
+            for (int i = lane; i < cnt * BODY_ROW; i += WAVE) s_tile[i] = b.rigid_body_state[(base + h * Q) * BODY_ROW + i];
         }
-        if (h == 0 && full) {  // next inputs on their way while the rows are picked apart
+        if (h == 0 && full) {
             load_chunks<CF4>(b.contact_forces + base * (NB * 3), r_cf, lane);
             load_chunks<ROOT4>(b.root_states + base * 13, r_root, lane);
         }
         if (h == 1 && full) load_chunks<DOF4>(b.dof_state + base * (2 * ND), r_dof, lane);
         wave_sync();
-        const int el = lane & (HALF - 1), part = lane >> 5;
-        if (el < cnt) {
-            const float *row = s_tile + el * BODY_ROW;
+        const int er = lane & (Q - 1), quarter = lane >> 4;
+        if (er < cnt) {
+            const float *row = s_tile + er * BODY_ROW;
             bool low = false;
-            const int b0 = part ? 8 : 0, b1 = part ? NB : 8;
+            const int b0 = 4 * quarter, b1 = b0 + 4 < NB ? b0 + 4 : NB;
             for (int body = b0; body < b1; ++body)
                 low |= (row[body * 13 + 2] < p.termination_height) && !is_contact_body(p, body);
-            if (low) atomicOr(&s_low[h * HALF + el], 1u);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int key = 2 * part + kk;
-                const float *kp = row + p.key_body_ids[key] * 13;
-                float *dst = s_key + (h * HALF + el) * (NK * 3) + key * 3;
-                dst[0] = kp[0]; dst[1] = kp[1]; dst[2] = kp[2];
-            }
+            if (low) atomicOr(&s_flag[h * Q + er], 1u);
+            const float *kp = row + p.key_body_ids[quarter] * 13;
+            float *dst = s_key + (h * Q + er) * (NK * 3) + quarter * 3;
+            dst[0] = kp[0]; dst[1] = kp[1]; dst[2] = kp[2];
         }
         wave_sync();
     }
 
-    // ---- contact forces and root rows through the tile: lane i takes environment i's rows
-    park_rows<NB * 3>(r_cf, b.contact_forces + base * (NB * 3), s_tile, nvalid, lane);
-    park_rows<13>(r_root, b.root_states + base * 13, s_tile + WAVE * NB * 3, nvalid, lane);
-    wave_sync();
-    float rr[13];
-    bool fall_contact = false;
-    {
-        const float *cf = s_tile + lane * (NB * 3);
-        for (int body = 0; body < NB; ++body) {
-            const bool hit = cf[3 * body] > 0.1f || cf[3 * body + 1] > 0.1f || cf[3 * body + 2] > 0.1f;
-            fall_contact |= hit && !is_contact_body(p, body);
+    // ---- contact forces and root rows through the tile
+    if (full) {
+#pragma unroll
+        for (int it = 0; it < (CF4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= CF4 || k < CF4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_cf[it];
         }
 #pragma unroll
-        for (int i = 0; i < 13; ++i) rr[i] = s_tile[WAVE * NB * 3 + lane * 13 + i];
+        for (int it = 0; it < (ROOT4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= ROOT4 || k < ROOT4) *reinterpret_cast<v4f *>(s_tile + T * NB * 3 + 4 * k) = r_root[it];
+        }
+    } else {
+        for (int i = lane; i < nvalid * NB * 3; i += WAVE) s_tile[i] = b.contact_forces[base * (NB * 3) + i];
+        for (int i = lane; i < nvalid * 13; i += WAVE) s_tile[T * NB * 3 + i] = b.root_states[base * 13 + i];
+    }
+    wave_sync();
+    float rr[13];
+    {
+        const float *cf = s_tile + el * (NB * 3);
+        bool hit_any = false;
+        const int b0 = part ? 8 : 0, b1 = part ? NB : 8;
+        for (int body = b0; body < b1; ++body) {
+            const bool hit = cf[3 * body] > 0.1f || cf[3 * body + 1] > 0.1f || cf[3 * body + 2] > 0.1f;
+            hit_any |= hit && !is_contact_body(p, body);
+        }
+        if (live && hit_any) atomicOr(&s_flag[el], 2u);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) rr[i] = s_tile[T * NB * 3 + el * 13 + i];
     }
     wave_sync();
 
-    // ---- dof_state: velocities to their final columns, positions parked inside the row
+    // ---- dof_state: velocities to their final columns, positions to the side buffer
     if (full) {
 #pragma unroll
         for (int it = 0; it < DOF4 / WAVE; ++it) {
             const int k = lane + it * WAVE;
-            const int pr = 2 * k;  // dof pair index within the tile: both dofs belong to one environment (ND even)
+            const int pr = 2 * k;
             const int env = pr / ND, j = pr - env * ND;
-            float *row = s_tile + env * NO;
-            row[POS_PARK + j] = r_dof[it].x; row[POS_PARK + j + 1] = r_dof[it].z;
-            row[65 + j] = r_dof[it].y; row[65 + j + 1] = r_dof[it].w;
+            s_pos[env * POS_STRIDE + j] = r_dof[it].x; s_pos[env * POS_STRIDE + j + 1] = r_dof[it].z;
+            s_tile[env * NO + 65 + j] = r_dof[it].y; s_tile[env * NO + 65 + j + 1] = r_dof[it].w;
         }
     } else {
         for (int i = lane; i < nvalid * ND; i += WAVE) {
             const int env = i / ND, j = i - env * ND;
             const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * ND + i];
-            s_tile[env * NO + POS_PARK + j] = pv.x;
+            s_pos[env * POS_STRIDE + j] = pv.x;
             s_tile[env * NO + 65 + j] = pv.y;
         }
     }
     wave_sync();
 
-    // ---- per-env: observation in place, reward, reset decision
+    // ---- per-env, split over the lane pair
     if (live) {
-        amp_obs_inplace(rr, s_key + lane * (NK * 3), p.local_root_obs != 0, s_tile + lane * NO);
-        prog += 1;
-        int64_t terminated = 0;
-        if (p.enable_early_termination && fall_contact && s_low[lane] != 0 && prog > 1) terminated = 1;
-        st_stream(b.rew + e, 1.0f);
-        st_stream(b.reset + e, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
-        st_stream(b.terminate + e, terminated);
-        st_stream(b.progress + e, prog);
+        float *row = s_tile + el * NO;
+        const float *pos = s_pos + el * POS_STRIDE;
+        const f3 root_pos{rr[0], rr[1], rr[2]};
+        const f4 root_rot{rr[3], rr[4], rr[5], rr[6]};
+        f4 heading_rot;
+        if (part == 0) {
+            float c[13];
+            root_obs(root_pos, root_rot, f3{rr[7], rr[8], rr[9]}, f3{rr[10], rr[11], rr[12]}, p.local_root_obs != 0,
+                     heading_rot, c);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) row[i] = c[i];
+        } else {
+            heading_rot = calc_heading_quat_inv(root_rot);
+            const float *key = s_key + el * (NK * 3);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const f3 l = quat_rotate<false>(heading_rot, f3{key[3 * k] - root_pos.x, key[3 * k + 1] - root_pos.y,
+                                                                key[3 * k + 2] - root_pos.z});
+                row[93 + 3 * k] = l.x; row[94 + 3 * k] = l.y; row[95 + 3 * k] = l.z;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int off = part ? PAIR_DOF_OFF[1][i] : PAIR_DOF_OFF[0][i];
+            float *dst = row + 13 + (part ? PAIR_OBS_OFF[1][i] : PAIR_OBS_OFF[0][i]);
+            if (i < 4) {  // 3-dof joints: exp map -> tangent / normal columns
+                float o6[6];
+                const float d[3] = {pos[off], pos[off + 1], pos[off + 2]};
+                joint_obs(d, 3, o6);
+                dst[0] = o6[0]; dst[1] = o6[1]; dst[2] = o6[2]; dst[3] = o6[3]; dst[4] = o6[4]; dst[5] = o6[5];
+            } else {
+                dst[0] = pos[off];
+            }
+        }
+        if (part == 0) {
+            prog += 1;
+            const unsigned f = s_flag[el];
+            int64_t terminated = 0;
+            if (p.enable_early_termination && (f & 2u) && (f & 1u) && prog > 1) terminated = 1;
+            const int64_t eo = base + el;
+            st_stream(b.rew + eo, 1.0f);
+            st_stream(b.reset + eo, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
+            st_stream(b.terminate + eo, terminated);
+            st_stream(b.progress + eo, prog);
+        }
     }
     wave_sync();
 
     // ---- observation rows out
     if (full && dev_aligned16(b.obs)) {
-        drain_rows<NO>(b.obs + base * NO, s_tile, nvalid, lane);
+        constexpr int N4 = T * NO / 4;
+        v4f *o4 = reinterpret_cast<v4f *>(b.obs + base * NO);
+#pragma unroll
+        for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= N4 || k < N4) st_stream(o4 + k, *reinterpret_cast<const v4f *>(s_tile + 4 * k));
+        }
     } else {
         for (int i = lane; i < nvalid * NO; i += WAVE) b.obs[base * NO + i] = s_tile[i];
     }
 
-    // ---- AMP history: slot k+1 <- slot k (newest first), slot 0 <- new observation
+    // ---- AMP history
     float *amp = b.amp_obs + base * K * NO;
     if (KK != 0 && full && dev_aligned16(b.amp_obs)) {
         constexpr int G = 16;
 #pragma unroll 1
-        for (int g0 = 0; g0 < WAVE; g0 += G) shift_history<KK ? KK : 2, G>(amp, s_tile, g0, lane);
+        for (int g0 = 0; g0 < T; g0 += G) shift_history<KK ? KK : 2, G>(amp, s_tile, g0, lane);
     } else {
         for (int k = K - 2; k >= 0; --k)
             for (int i = lane; i < nvalid * NO; i += WAVE) {
@@ -613,14 +644,14 @@ extern "C" int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buff
     int rc = check_amp(p, b, n, "igx_humanoid_amp_step");
     if (rc != IGX_OK || n == 0) return rc;
     if (!b->contact_forces || !b->rew) return fail(IGX_E_NULL, "igx_humanoid_amp_step: contact_forces / rew is NULL");
-    const dim3 grid((unsigned)((n + WAVE - 1) / WAVE));
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int reserve = tuning_int("IGX_AMP_LDS_RESERVE", 0);  // unused LDS: caps the waves per CU
+    const dim3 g2((unsigned)((n + PAIR_T - 1) / PAIR_T));
     switch (p->num_amp_obs_steps) {
-    case 2: hipLaunchKernelGGL(amp_step_kernel<2>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
-    case 3: hipLaunchKernelGGL(amp_step_kernel<3>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
-    case 4: hipLaunchKernelGGL(amp_step_kernel<4>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
-    default: hipLaunchKernelGGL(amp_step_kernel<0>, grid, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    case 2: hipLaunchKernelGGL(amp_step_pair_kernel<2>, g2, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    case 3: hipLaunchKernelGGL(amp_step_pair_kernel<3>, g2, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    case 4: hipLaunchKernelGGL(amp_step_pair_kernel<4>, g2, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
+    default: hipLaunchKernelGGL(amp_step_pair_kernel<0>, g2, dim3(WAVE), (size_t)reserve, s, *p, *b, n); break;
     }
     return launch_status("igx_humanoid_amp_step");
 }
