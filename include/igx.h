@@ -386,6 +386,30 @@ const float *igx_recorder_host_data(const igx_recorder *r);
 int igx_recorder_destroy(igx_recorder *r);
 
 /* ------------------------------------------------------------------------
+ * Episode statistics (learning/common_agent.py:284-296 game_rewards /
+ * game_lengths; utils/rlgames_utils.py:151-174): per step
+ *   current_rewards += rew; current_lengths += 1;
+ *   done envs contribute (1, current_rewards, current_lengths) to the totals;
+ *   current_rewards *= 1 - done; current_lengths *= 1 - done.
+ * workspace: IGX_EPISODE_WORKSPACE_BYTES(n_envs), 16-byte aligned; its first
+ * record {uint64 n_done; double sum_reward; double sum_length; uint64 steps}
+ * is the running total since the caller last zeroed it (zero it before the first
+ * call), the second the totals of the last call.  Shards of a multi-GPU job
+ * all-gather their first records and add them.
+ * ---------------------------------------------------------------------- */
+#define IGX_EPISODE_RECORD_BYTES 32
+#define IGX_EPISODE_WORKSPACE_BYTES(n_envs) (32 * (((int64_t)(n_envs) + 255) / 256 + 2))
+typedef struct igx_episode_buffers {
+    const float *rew;          /* [N] */
+    const int64_t *done;       /* [N] the reset flags returned by step() */
+    float *current_rewards;    /* [N] in/out */
+    float *current_lengths;    /* [N] in/out */
+    void *workspace;
+} igx_episode_buffers;
+
+int igx_episode_stats_step(const igx_episode_buffers *b, int64_t n_envs, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * torch_jit_utils math, one batched call per reference function
  * (utils/torch_jit_utils.py).  Quaternions are [n,4] xyzw, vectors [n,3],
  * all fp32 contiguous; `out` may alias an input of the same shape.

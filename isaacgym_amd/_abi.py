@@ -148,6 +148,10 @@ class VecTaskTail(_Struct):
                 ("max_episode_length_m1", C.c_double), ("clip_obs", f32), ("reserved", i32)]
 
 
+class EpisodeBuffers(_Struct):
+    _fields_ = [("rew", ptr), ("done", ptr), ("current_rewards", ptr), ("current_lengths", ptr), ("workspace", ptr)]
+
+
 def make_buffers(cls, arrays, ptr_of):
     """Build a *Buffers struct from a name->array mapping.
 

@@ -35,6 +35,7 @@ SYMBOLS = {
 }
 SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])
+SYMBOLS["igx_episode_stats_step"] = (C.c_int, [_P, C.c_int64, _P])
 # trajectory recorder
 SYMBOLS.update({
     "igx_recorder_create": (C.c_int, [C.POINTER(_P), C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64]),
@@ -111,7 +112,7 @@ def tensor_ptr(t, dtype=None):
 
 
 _I64_FIELDS = {"reset", "progress", "randomize", "reset_goal", "terminate", "motion_ids", "frame_idx0",
-               "frame_idx1", "object_indices", "goal_object_indices", "env_ids"}
+               "frame_idx1", "object_indices", "goal_object_indices", "env_ids", "done"}
 _RAW_FIELDS = {"workspace"}  # opaque device scratch: any dtype
 _F64_FIELDS = {"motion_times"}
 

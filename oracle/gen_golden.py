@@ -986,7 +986,47 @@ def gen_vectask(seed=21, N=301, T=3):
     print("vectask.npz", {k: (v.shape, v.dtype) for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"vectask": gen_vectask, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+def gen_episode_stats(seed=31, N=777, T=6):
+    """The reward / length bookkeeping at learning/common_agent.py:284-296.  That module imports
+    rl_games (absent), so the expressions of the call site are evaluated here with torch on
+    CPU, statement by statement: current_rewards += rewards; current_lengths += 1;
+    done_indices = dones.nonzero(); update(current_rewards[done_indices]) (sum and count recorded);
+    not_dones = 1.0 - dones.float(); current_rewards *= not_dones.unsqueeze(1); current_lengths *= not_dones."""
+    g = torch.Generator().manual_seed(seed)
+    current_rewards = torch.zeros(N, 1)
+    current_lengths = torch.zeros(N)
+    out = {k: [] for k in ("rew", "dones", "current_rewards", "current_lengths", "n_done", "mean_reward", "mean_length",
+                           "sum_reward", "sum_length")}
+    for t in range(T):
+        rewards = torch.randn(N, 1, generator=g) * 3.0
+        dones = (torch.rand(N, generator=g) < 0.08).to(torch.uint8)
+        if t == 3:
+            dones.zero_()  # a step without finished episodes
+        current_rewards += rewards
+        current_lengths += 1
+        all_done_indices = dones.nonzero(as_tuple=False)
+        done_indices = all_done_indices[::1]
+        vals_r = current_rewards[done_indices]
+        vals_l = current_lengths[done_indices]
+        out["n_done"].append(np.int64(vals_r.numel()))
+        out["mean_reward"].append(vals_r.mean().numpy() if vals_r.numel() else np.float32("nan"))
+        out["mean_length"].append(vals_l.mean().numpy() if vals_l.numel() else np.float32("nan"))
+        out["sum_reward"].append(vals_r.double().sum().numpy())
+        out["sum_length"].append(vals_l.double().sum().numpy())
+        not_dones = 1.0 - dones.float()
+        current_rewards = current_rewards * not_dones.unsqueeze(1)
+        current_lengths = current_lengths * not_dones
+        out["rew"].append(rewards.squeeze(1).numpy().copy())
+        out["dones"].append(dones.numpy().astype(np.int64))
+        out["current_rewards"].append(current_rewards.squeeze(1).numpy().copy())
+        out["current_lengths"].append(current_lengths.numpy().copy())
+    res = {k: np.stack([np.asarray(x) for x in v]) for k, v in out.items()}
+    res["meta"] = _meta(task="EpisodeStats", N=N, T=T, seed=seed)
+    np.savez_compressed(os.path.join(OUT, "episode_stats.npz"), **res)
+    print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
+
+
+GENERATORS = {"vectask": gen_vectask, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

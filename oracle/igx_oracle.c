@@ -1062,3 +1062,26 @@ int orc_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, co
     }
     return 0;
 }
+
+/* ------------------------------------------------------- episode statistics --- */
+/* learning/common_agent.py:284-296: current_rewards += rewards; current_lengths += 1;
+ * totals over done envs; current_* *= (1 - done).  out = {n_done, sum_reward, sum_length}. */
+int orc_episode_stats_step(const igx_episode_buffers *b, int64_t n, double out[3])
+{
+    int64_t cnt = 0;
+    double sr = 0.0, sl = 0.0;
+    for (int64_t e = 0; e < n; ++e) {
+        const float not_done = 1.0f - (b->done[e] != 0 ? 1.0f : 0.0f);
+        const float cr = b->current_rewards[e] + b->rew[e];
+        const float cl = b->current_lengths[e] + 1.0f;
+        if (not_done == 0.0f) {
+            cnt += 1;
+            sr += (double)cr;
+            sl += (double)cl;
+        }
+        b->current_rewards[e] = cr * not_done;
+        b->current_lengths[e] = cl * not_done;
+    }
+    out[0] = (double)cnt; out[1] = sr; out[2] = sl;
+    return 0;
+}

@@ -199,3 +199,11 @@ def vec_task_tail(obs_buf, clip_obs, progress, reset, max_episode_length):
     clip = np.float32(clip_obs)
     out = np.minimum(np.maximum(obs_buf, -clip), clip).astype(np.float32)
     return out, (progress >= max_episode_length - 1) & (reset != 0)
+
+
+def episode_stats_step(bufs, n):
+    """In place on current_rewards / current_lengths; returns (n_done, sum_reward, sum_length)."""
+    b = _abi.make_buffers(_abi.EpisodeBuffers, bufs, _np_ptr)
+    out = (C.c_double * 3)()
+    assert lib().orc_episode_stats_step(C.byref(b), C.c_int64(n), out) == 0
+    return int(out[0]), float(out[1]), float(out[2])

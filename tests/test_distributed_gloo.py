@@ -76,6 +76,21 @@ def _allegro_rank(rank, world, port, n, outdir):
         records = distributed.gather_records(rec)
         assert records.shape == (world, 16)
         oracle.allegro_finalize_shards(p, mine, records.numpy())
+    # episode statistics: one 32-byte record per rank, gathered and added in rank order
+    from isaacgym_amd.episode_stats import sum_records
+    rng = np.random.default_rng(5)
+    rew, done = rng.standard_normal(n).astype(np.float32), (rng.random(n) < 0.2).astype(np.int64)
+    k, sr, sl = oracle.episode_stats_step(dict(rew=rew[start:start + count].copy(), done=done[start:start + count].copy(),
+                                               current_rewards=np.zeros(count, np.float32),
+                                               current_lengths=np.zeros(count, np.float32),
+                                               workspace=np.zeros(8, np.int64)), count)
+    rec = torch.tensor([k, 0, 0, 1], dtype=torch.int64)
+    rec[1:3] = torch.tensor([sr, sl], dtype=torch.float64).view(torch.int64)
+    tot = sum_records(distributed.gather_records(rec))
+    kf, srf, slf = oracle.episode_stats_step(dict(rew=rew.copy(), done=done.copy(), current_rewards=np.zeros(n, np.float32),
+                                                  current_lengths=np.zeros(n, np.float32),
+                                                  workspace=np.zeros(8, np.int64)), n)
+    assert tot[0] == kf and tot[2] == slf and abs(tot[1] - srf) < 1e-9 * max(1.0, abs(srf)) and tot[3] == 1
     # imitation batches: per-rank rows concatenated in rank order
     rows = distributed.all_gather_rows(torch.full((4, 3), float(rank)))
     assert rows.shape == (4 * world, 3) and torch.equal(rows[::4, 0], torch.arange(world, dtype=torch.float32))
