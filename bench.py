@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+METRIC = "env-steps/sec obs+reward+reset (Ant, 1M envs) at 1/2/4/8 GPUs; % HBM roofline"
 ENVS_PER_GPU = 1 << 20
 ANT_BYTES_PER_ENV_STEP = 556      # read 264 + write 292 (obs/reward/reset path of one Ant env)
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak
@@ -39,6 +40,9 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--task", default="ant", choices=["ant", "humanoid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--episode-stats", action="store_true",
+                    help="also run the episode-statistics kernel every step (inside the timed region) and "
+                         "all-gather the totals over the ranks afterwards")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample size in steps (0 = auto)")
     return ap.parse_args()
 
@@ -113,10 +117,17 @@ def main():
                   "heading_vec", "rew"):
             s[k] = sets[0][k]
 
+    es = None
+    if args.episode_stats:
+        from isaacgym_amd.episode_stats import EpisodeStats
+        es = EpisodeStats(n, dev)
+
     def run(k0, k):
         for i in range(k0, k0 + k):
             p.rng_offset = i
             step(p, sets[i % NUM_INPUT_SETS], n)
+            if es is not None:
+                es.step(sets[0]["rew"], sets[0]["reset"])
 
     def barrier():
         if world > 1:
@@ -140,13 +151,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    stats = es.totals() if es is not None else None  # one 32-byte-per-rank all-gather (RCCL when world > 1)
+
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
         value = total_env_steps / elapsed
         bytes_per_env = ANT_BYTES_PER_ENV_STEP if args.task == "ant" else 940
         achieved = n * bytes_per_env / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec obs+reward+reset (Ant, 1M envs) at 1/2/4/8 GPUs; % HBM roofline",
+            "metric": METRIC if args.task == "ant" else METRIC.replace("Ant", args.task.capitalize()),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -159,6 +172,10 @@ def main():
                          "traffic": load_traffic() if args.task == "ant" and n == ENVS_PER_GPU else None,
                          "kernel_ms": kernel_ms, "bytes_per_env_step": bytes_per_env},
         }
+        if stats is not None:
+            out["episode_stats"] = {"episodes_finished": stats[0], "mean_reward": stats[1] / max(stats[0], 1),
+                                    "mean_length": stats[2] / max(stats[0], 1), "steps": stats[3],
+                                    "note": "extra kernel inside the timed region; totals all-gathered over the ranks"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, n, args.task)
         print(json.dumps(out), flush=True)
