@@ -153,6 +153,51 @@ int igx_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b,
                       int64_t n_envs, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * AntImitate (tasks/ant_imitate.py): the Ant step with the pose-imitation
+ * reward (:447-555, JUST_MEASURE_POSE_SIMILARITY branch) in place of the
+ * locomotion reward.  post_physics_step (:405-419): target_pose_idx += 1,
+ * progress / randomize += 1, flagged resets, observations (as Ant), then
+ *   pose_diff = sum_j |obs[12+j] - unscale(motion[target_pose_idx][j])|   (fp64:
+ *               the motion comes from np.loadtxt and the arithmetic promotes)
+ *   reward = exp(-pose_diff); death_cost below the termination height;
+ *   threshold = max(distance_floor, quantile(pose_diff over ALL envs, q));
+ *   pose_diff > threshold: reset = 1, reward = death_cost, target_pose_idx = 0;
+ *   target_pose_idx >= num_frames - 3: reward = -3 * death_cost, target_pose_idx = 0.
+ * The global quantile is an exact radix select (both neighbouring order
+ * statistics, torch.quantile's linear interpolation).
+ * ---------------------------------------------------------------------- */
+typedef struct igx_imitate_args {
+    const double *motion;       /* [num_frames, 8] fp64 joint targets */
+    int64_t num_frames;
+    int64_t *target_pose_idx;   /* [N] in/out */
+    double *pose_diff;          /* [N] out */
+    void *workspace;            /* IGX_QUANTILE_WORKSPACE_BYTES, 16-byte aligned, any contents */
+    double quantile;            /* 0.99 */
+    double distance_floor;      /* 1.8 */
+    double death_cost;          /* env.deathCost as the double the reference multiplies with */
+    int64_t n_total;            /* environments over all shards (== n_envs on one GPU) */
+} igx_imitate_args;
+
+#define IGX_QUANTILE_WORKSPACE_BYTES (64 + 2 * 2048 * 8)
+
+/* everything in one call (one GPU) */
+int igx_ant_imitate_step(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
+                         int64_t n_envs, igx_stream_t stream);
+/* the pieces, for environment-sharded runs: observe; then for pass = 0..5 { histogram;
+ * all-reduce(sum) of the 2 x 2048 uint64 at workspace + 64 over the ranks; advance }; finish.
+ * igx_quantile_begin zeroes the state and sets the two ranks from q and n_total. */
+int igx_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
+                            int64_t n_envs, igx_stream_t stream);
+int igx_ant_imitate_finish(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
+                           int64_t n_envs, igx_stream_t stream);
+int igx_quantile_begin(void *workspace, double q, int64_t n_total, igx_stream_t stream);
+int igx_quantile_histogram(const double *x, int64_t n, void *workspace, int32_t pass, igx_stream_t stream);
+int igx_quantile_advance(void *workspace, int32_t pass, igx_stream_t stream);
+#define IGX_QUANTILE_PASSES 6
+/* torch.quantile(x, q) (linear interpolation) of n doubles -> *out (device); x must hold no NaN */
+int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * AllegroHand in-hand reorientation.
  * Two entry points, as the reference splits the work (tasks/allegro_hand.py):
  *  igx_allegro_pre_physics  = pre_physics_step :586-615 with reset_target_pose

@@ -148,6 +148,15 @@ class VecTaskTail(_Struct):
                 ("max_episode_length_m1", C.c_double), ("clip_obs", f32), ("reserved", i32)]
 
 
+class ImitateArgs(_Struct):
+    _fields_ = [("motion", ptr), ("num_frames", i64), ("target_pose_idx", ptr), ("pose_diff", ptr), ("workspace", ptr),
+                ("quantile", C.c_double), ("distance_floor", C.c_double), ("death_cost", C.c_double), ("n_total", i64)]
+
+
+IGX_QUANTILE_WORKSPACE_BYTES = 64 + 2 * 2048 * 8
+IGX_QUANTILE_PASSES = 6
+
+
 class EpisodeBuffers(_Struct):
     _fields_ = [("rew", ptr), ("done", ptr), ("current_rewards", ptr), ("current_lengths", ptr), ("workspace", ptr)]
 

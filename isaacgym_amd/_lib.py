@@ -35,6 +35,15 @@ SYMBOLS = {
 }
 SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])
+SYMBOLS.update({
+    "igx_ant_imitate_step": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "igx_ant_imitate_observe": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "igx_ant_imitate_finish": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "igx_quantile_begin": (C.c_int, [_P, C.c_double, C.c_int64, _P]),
+    "igx_quantile_histogram": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P]),
+    "igx_quantile_advance": (C.c_int, [_P, C.c_int32, _P]),
+    "igx_quantile_f64": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
+})
 SYMBOLS["igx_episode_stats_step"] = (C.c_int, [_P, C.c_int64, _P])
 # trajectory recorder
 SYMBOLS.update({

@@ -22,6 +22,13 @@ _TASKS = {
                  terminationHeight=0.31, plane=dict(staticFriction=1.0, dynamicFriction=1.0, restitution=0.0),
                  enableCameraSensors=False),
         sim=_SIM, task=dict(randomize=False, randomization_params={})),
+    "AntImitate": dict(
+        env=dict(numEnvs=4096, envSpacing=5, episodeLength=1000, enableDebugVis=False, clipActions=1.0, powerScale=1.0,
+                 controlFrequencyInv=1, headingWeight=0.5, upWeight=0.1, actionsCost=0.005, energyCost=0.05,
+                 dofVelocityScale=0.2, contactForceScale=0.1, jointsAtLimitCost=0.1, deathCost=-2.0,
+                 terminationHeight=0.31, plane=dict(staticFriction=1.0, dynamicFriction=1.0, restitution=0.0),
+                 enableCameraSensors=False, camera_outdir=""),
+        sim=_SIM, task=dict(randomize=False, randomization_params={})),
     "Humanoid": dict(
         env=dict(numEnvs=4096, envSpacing=5, episodeLength=1000, enableDebugVis=False, clipActions=1.0, powerScale=1.0,
                  headingWeight=0.5, upWeight=0.1, actionsCost=0.01, energyCost=0.05, dofVelocityScale=0.1,

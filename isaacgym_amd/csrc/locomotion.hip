@@ -100,8 +100,8 @@ __device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx
 
 // What lane i computes for environment e from its root row (13 registers) and
 // its LDS observation row.  Returns up_vec / heading_vec for the drain.
-template <int D, int S, bool HUM, int T>
-__device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco_buffers &b, int64_t e,
+template <int D, int S, bool HUM, int T, bool IMIT>
+__device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco_buffers &b, const igx_imitate_args &im, int64_t e,
                                         const float (&rr)[13], int64_t prog, int64_t rst, int64_t rnd, float pot,
                                         float *row, const float *s_lim, f3 &up_vec, f3 &heading_vec)
 {
@@ -163,7 +163,26 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
     const float actions_cost = row_sum<D>(tmp);
     const float progress_reward = pot - prev_pot;
     float total;
-    if constexpr (!HUM) {
+    if constexpr (IMIT) {
+        // tasks/ant_imitate.py:508-519: fp64 throughout (the motion table is fp64 and promotes)
+        static_assert(D == 8 && !HUM, "AntImitate is the 8-dof Ant");
+        int64_t idx = im.target_pose_idx[e] + 1;  // :408
+        im.target_pose_idx[e] = idx;
+        idx = idx < 0 ? 0 : (idx >= im.num_frames ? im.num_frames - 1 : idx);
+        const double *m = im.motion + idx * D;
+        double diff[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double lo = (double)s_lim[j], hi = (double)s_lim[D + j];
+            const double span = (double)(s_lim[D + j] - s_lim[j]);  // upper - lower is an fp32 subtraction
+            const double scaled = (2.0 * m[j] - hi - lo) / span;
+            diff[j] = fabs((double)dpos[j] - scaled);
+        }
+        // torch.sum over 8 doubles: 4 vector lanes over the two blocks of 4, lanes left to right
+        const double pose_diff = (((diff[0] + diff[4]) + (diff[1] + diff[5])) + (diff[2] + diff[6])) + (diff[3] + diff[7]);
+        im.pose_diff[e] = pose_diff;
+        total = (float)exp(-pose_diff);
+    } else if constexpr (!HUM) {
 #pragma unroll
         for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * dvel[j]);
         const float electricity_cost = row_sum<D>(tmp);
@@ -187,7 +206,7 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
                 p.energy_cost_scale * electricity_cost - dof_at_limit_cost;
     }
     if (pos.z < p.termination_height) {
-        total = p.death_cost;
+        total = IMIT ? (float)im.death_cost : p.death_cost;
         rst = 1;
     }
     if ((float)prog >= p.max_episode_length_m1) rst = 1;
@@ -236,8 +255,9 @@ __device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t bas
     }
 }
 
-template <int D, int S, bool HUM, int T>
-__global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p, const igx_loco_buffers b, int64_t n)
+template <int D, int S, bool HUM, int T, bool IMIT>
+__global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p, const igx_loco_buffers b, int64_t n,
+                                                         const igx_imitate_args im)
 {
     using L = LocoLayout<D, S, HUM, T>;
     constexpr int NOBS = L::NOBS;
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
 
         // ---- per-env math
         f3 up_vec{0, 0, 0}, heading_vec{0, 0, 0};
-        if (live) per_env<D, S, HUM, T>(p, b, e, rr, prog, rst, rnd, pot, s_tile + lane * NOBS, s_lim, up_vec, heading_vec);
+        if (live) per_env<D, S, HUM, T, IMIT>(p, b, im, e, rr, prog, rst, rnd, pot, s_tile + lane * NOBS, s_lim, up_vec, heading_vec);
         wave_sync();
 
         // ---- drain: finished rows out as whole lines
@@ -453,15 +473,16 @@ static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64
     return IGX_OK;
 }
 
-template <int D, int S, bool HUM, int T>
+template <int D, int S, bool HUM, int T, bool IMIT = false>
 static int launch_loco_tile(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int lds_reserve,
-                            igx_stream_t stream, const char *who)
+                            igx_stream_t stream, const char *who, const igx_imitate_args *im = nullptr)
 {
     const int64_t tiles = (n + T - 1) / T;
     if (tiles > 0x7fffffffLL) return fail(IGX_E_SIZE, "%s: n_envs too large for one launch", who);
     const int64_t blocks = (tiles + IGX_LOCO_TPW - 1) / IGX_LOCO_TPW;
-    hipLaunchKernelGGL((loco_step_kernel<D, S, HUM, T>), dim3((unsigned)blocks), dim3(WAVE), (size_t)lds_reserve,
-                       static_cast<hipStream_t>(stream), *p, *b, n);
+    const igx_imitate_args none = {};
+    hipLaunchKernelGGL((loco_step_kernel<D, S, HUM, T, IMIT>), dim3((unsigned)blocks), dim3(WAVE), (size_t)lds_reserve,
+                       static_cast<hipStream_t>(stream), *p, *b, n, im ? *im : none);
     return launch_status(who);
 }
 
@@ -483,7 +504,76 @@ static int launch_loco(const igx_loco_params *p, const igx_loco_buffers *b, int6
     return launch_loco_tile<D, S, HUM, 64>(p, b, n, reserve, stream, who);
 }
 
+// tasks/ant_imitate.py:523-555: the decisions that need the global threshold
+__global__ __launch_bounds__(256) void imitate_finish_kernel(const igx_loco_buffers b, const igx_imitate_args im, int64_t n)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const double q = reinterpret_cast<const double *>(im.workspace)[5];  // QuantileState::result
+    const double thr = im.distance_floor > q ? im.distance_floor : q;    // max(1.8, quantile)
+    const double d = ld_stream(im.pose_diff + e);
+    int64_t idx = im.target_pose_idx[e];
+    const bool far = d > thr;
+    const bool finished = (far ? 0 : idx) >= im.num_frames - 3;
+    if (far) {
+        b.reset[e] = 1;
+        b.rew[e] = (float)im.death_cost;
+        idx = 0;
+    }
+    if (finished) {
+        b.rew[e] = (float)(-3.0 * im.death_cost);
+        idx = 0;
+    }
+    if (far || finished) im.target_pose_idx[e] = idx;
+}
+
+static int check_imitate(const igx_imitate_args *im, int64_t n, const char *who)
+{
+    if (!im) return fail(IGX_E_NULL, "%s: imitate args struct is NULL", who);
+    if (im->num_frames < 4) return fail(IGX_E_PARAM, "%s: the motion needs at least 4 frames", who);
+    if (!(im->quantile >= 0.0 && im->quantile <= 1.0)) return fail(IGX_E_PARAM, "%s: quantile outside [0, 1]", who);
+    if (im->n_total < n) return fail(IGX_E_SIZE, "%s: n_total %lld < n_envs %lld", who, (long long)im->n_total, (long long)n);
+    if (n == 0) return IGX_OK;
+    if (!im->motion || !im->target_pose_idx || !im->pose_diff || !im->workspace)
+        return fail(IGX_E_NULL, "%s: motion / target_pose_idx / pose_diff / workspace is NULL", who);
+    if (!aligned16(im->workspace)) return fail(IGX_E_ALIGN, "%s: workspace must be 16-byte aligned", who);
+    return IGX_OK;
+}
+
 }  // namespace igx
+
+extern "C" int igx_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
+                                       int64_t n_envs, igx_stream_t stream)
+{
+    int rc = igx::check_loco(p, b, n_envs, 8, 24, false, "igx_ant_imitate_observe");
+    if (rc == IGX_OK) rc = igx::check_imitate(im, n_envs, "igx_ant_imitate_observe");
+    if (rc != IGX_OK || n_envs == 0) return rc;
+    static const int reserve = igx::tuning_int("IGX_ANT_LDS_RESERVE", 13000);
+    return igx::launch_loco_tile<8, 24, false, 64, true>(p, b, n_envs, reserve, stream, "igx_ant_imitate_observe", im);
+}
+
+extern "C" int igx_ant_imitate_finish(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
+                                      int64_t n_envs, igx_stream_t stream)
+{
+    if (!p || !b) return igx::fail(IGX_E_NULL, "igx_ant_imitate_finish: params/buffers struct is NULL");
+    int rc = igx::check_imitate(im, n_envs, "igx_ant_imitate_finish");
+    if (rc != IGX_OK || n_envs == 0) return rc;
+    if (!b->reset || !b->rew) return igx::fail(IGX_E_NULL, "igx_ant_imitate_finish: reset / rew is NULL");
+    hipLaunchKernelGGL(igx::imitate_finish_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *b, *im, n_envs);
+    return igx::launch_status("igx_ant_imitate_finish");
+}
+
+extern "C" int igx_ant_imitate_step(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
+                                    int64_t n_envs, igx_stream_t stream)
+{
+    int rc = igx_ant_imitate_observe(p, b, im, n_envs, stream);
+    if (rc != IGX_OK || n_envs == 0) return rc;
+    double *result = reinterpret_cast<double *>(im->workspace) + 5;  // the quantile lands in the state itself
+    rc = igx_quantile_f64(im->pose_diff, n_envs, im->quantile, result, im->workspace, stream);
+    if (rc != IGX_OK) return rc;
+    return igx_ant_imitate_finish(p, b, im, n_envs, stream);
+}
 
 extern "C" int igx_ant_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n_envs, igx_stream_t stream)
 {

@@ -160,3 +160,72 @@ def clamp(x, lo, hi, out):
         rc = _lib.lib().igx_clamp(_lib.tensor_ptr(x, torch.float32), C.c_float(lo), C.c_float(hi),
                                   _lib.tensor_ptr(out, torch.float32), C.c_int64(x.numel()), _lib.current_stream(dev))
     _lib.check(rc)
+
+
+# ---- AntImitate / global quantile ---------------------------------------------------------
+def imitate_args(motion, target_pose_idx, pose_diff, workspace, quantile, distance_floor, death_cost, n_total=None):
+    """igx_imitate_args over device tensors (motion [F,8] f64, target_pose_idx [n] i64, pose_diff [n] f64,
+    workspace >= IGX_QUANTILE_WORKSPACE_BYTES)."""
+    if workspace.numel() * workspace.element_size() < _abi.IGX_QUANTILE_WORKSPACE_BYTES:
+        raise ValueError("workspace smaller than IGX_QUANTILE_WORKSPACE_BYTES")
+    if motion.dim() != 2 or motion.shape[1] != 8:
+        raise ValueError("motion must be [num_frames, 8]")
+    n = target_pose_idx.shape[0]
+    if pose_diff.shape[0] != n:
+        raise ValueError("pose_diff and target_pose_idx must have one entry per environment")
+    return _abi.ImitateArgs(motion=_lib.tensor_ptr(motion, torch.float64), num_frames=motion.shape[0],
+                            target_pose_idx=_lib.tensor_ptr(target_pose_idx, torch.int64),
+                            pose_diff=_lib.tensor_ptr(pose_diff, torch.float64), workspace=_lib.tensor_ptr(workspace),
+                            quantile=quantile, distance_floor=distance_floor, death_cost=death_cost,
+                            n_total=n if n_total is None else n_total)
+
+
+def _imitate_call(symbol, params, tensors, im, n_envs):
+    b, dev = _lib.make_buffers(_abi.LocoBuffers, tensors)
+    with torch.cuda.device(dev):
+        rc = getattr(_lib.lib(), symbol)(C.byref(params), C.byref(b), C.byref(im), C.c_int64(n_envs),
+                                         _lib.current_stream(dev))
+    _lib.check(rc)
+
+
+def ant_imitate_step(params, tensors, im, n_envs):
+    _imitate_call("igx_ant_imitate_step", params, tensors, im, n_envs)
+
+
+def ant_imitate_observe(params, tensors, im, n_envs):
+    _imitate_call("igx_ant_imitate_observe", params, tensors, im, n_envs)
+
+
+def ant_imitate_finish(params, tensors, im, n_envs):
+    _imitate_call("igx_ant_imitate_finish", params, tensors, im, n_envs)
+
+
+def quantile_f64(x, q, workspace=None):
+    """torch.quantile(x, q) of a 1-D fp64 device tensor (no NaN): exact radix select; returns a 0-dim tensor."""
+    dev = x.device
+    if workspace is None:
+        workspace = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=dev)
+    out = torch.empty((), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_quantile_f64(_lib.tensor_ptr(x, torch.float64), C.c_int64(x.numel()), C.c_double(q),
+                                         _lib.tensor_ptr(out), _lib.tensor_ptr(workspace), _lib.current_stream(dev))
+    _lib.check(rc)
+    return out
+
+
+def quantile_sharded(x, q, n_total, workspace, all_reduce):
+    """The same select over the shards of a multi-GPU job: `all_reduce(hist)` must sum the int64 histogram
+    tensor over the ranks in place (torch.distributed.all_reduce).  The result is left in the workspace
+    state (read by ant_imitate_finish) and returned as a 0-dim tensor."""
+    dev = workspace.device
+    L = _lib.lib()
+    ws = _lib.tensor_ptr(workspace)
+    hist = workspace.view(torch.int64)[8:8 + 2 * 2048]
+    with torch.cuda.device(dev):
+        st = _lib.current_stream(dev)
+        _lib.check(L.igx_quantile_begin(ws, C.c_double(q), C.c_int64(n_total), st))
+        for p in range(_abi.IGX_QUANTILE_PASSES):
+            _lib.check(L.igx_quantile_histogram(_lib.tensor_ptr(x, torch.float64), C.c_int64(x.numel()), ws, C.c_int32(p), st))
+            all_reduce(hist)
+            _lib.check(L.igx_quantile_advance(ws, C.c_int32(p), st))
+    return workspace.view(torch.float64)[5].clone()

@@ -55,6 +55,7 @@ _PHYSICS_OWNED = {
     "Cartpole": ("dof_state",),
     "CartpoleSample": ("dof_state",),
     "Ant": ("root_states", "dof_state", "sensors"),
+    "AntImitate": ("root_states", "dof_state", "sensors"),
     "Humanoid": ("root_states", "dof_state", "sensors", "dof_force"),
     "AllegroHand": ("dof_state", "dof_force", "root_state_tensor"),
     "HumanoidAMP": ("root_states", "dof_state", "rigid_body_state", "contact_forces"),
@@ -64,7 +65,7 @@ _PHYSICS_OWNED = {
 def _draw(task, n, seed, device, **kw):
     if task in ("Cartpole", "CartpoleSample"):
         return synthetic.cartpole_state(n, seed, device)
-    if task == "Ant":
+    if task in ("Ant", "AntImitate"):
         return synthetic.loco_state(synthetic.ANT, n, seed, device)
     if task == "Humanoid":
         return synthetic.loco_state(synthetic.HUMANOID, n, seed, device)
@@ -89,8 +90,8 @@ class SyntheticSim(TensorSim):
         for i in range(1, num_sets):
             nxt = _draw(task, num_envs, seed + 1000 * i, self.device, **kw)
             self._sets.append({k: nxt[k] for k in owned})
-        if task in ("Ant", "Humanoid"):
-            spec = synthetic.ANT if task == "Ant" else synthetic.HUMANOID
+        if task in ("Ant", "AntImitate", "Humanoid"):
+            spec = synthetic.HUMANOID if task == "Humanoid" else synthetic.ANT
             lo, hi = synthetic.loco_limits(spec["num_dof"])
             p = synthetic.loco_params(spec)
             self.asset = dict(dof_limits_lower=lo, dof_limits_upper=hi,

@@ -1,6 +1,7 @@
 """Task classes with the reference's names (tasks/__init__.py: isaacgym_task_map)."""
 from .allegro_hand import AllegroHand
 from .ant import Ant
+from .ant_imitate import AntImitate
 from .cartpole import Cartpole
 from .cartpole_sample import CartpoleSample
 from .humanoid import Humanoid
@@ -9,6 +10,7 @@ from .humanoid_amp import HumanoidAMP
 isaacgym_task_map = {
     "AllegroHand": AllegroHand,
     "Ant": Ant,
+    "AntImitate": AntImitate,
     "Cartpole": Cartpole,
     "CartpoleSample": CartpoleSample,
     "Humanoid": Humanoid,
@@ -29,4 +31,9 @@ def make(name, num_envs, device="cuda:0", seed=0, sim=None, **env_overrides):
             extra["num_amp_obs_steps"] = cfg["env"]["numAMPObsSteps"]
         sim = SyntheticSim(name, num_envs, device, seed=seed, **extra)
     kw = {} if name == "HumanoidAMP" else dict(seed=seed)
+    if name == "AntImitate" and "motionToImitate" not in cfg:
+        import numpy as np
+        from .. import synthetic
+        lo, hi = (np.asarray(v, np.float64) for v in synthetic.loco_limits(8))
+        kw["motion"] = lo + (hi - lo) * np.random.default_rng(seed).random((64, 8))
     return isaacgym_task_map[name](cfg, device, device, 0, True, False, False, sim=sim, **kw)

@@ -1,0 +1,55 @@
+"""AntImitate: the fork's pose-imitation variant of Ant (reference tasks/ant_imitate.py).
+Observations as Ant; the reward is exp(-|joint pose - target frame|_1) with a reset
+threshold at max(1.8, 0.99-quantile over ALL environments) (:447-555), evaluated in
+fp64 like the reference (its motion table comes from np.loadtxt).  One fused kernel, an
+exact device quantile (radix select; histograms all-reduced over the ranks of an
+environment-sharded job) and one finishing kernel per step."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _abi, distributed, ops
+from .locomotion import Ant
+
+
+class AntImitate(Ant):
+    QUANTILE_THRESHOLD = 0.99
+    DISTANCE_FLOOR = 1.8
+
+    def __init__(self, cfg, rl_device, sim_device, graphics_device_id=0, headless=True, virtual_screen_capture=False,
+                 force_render=False, sim=None, seed=0, motion=None, process_group=None):
+        super().__init__(cfg, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture,
+                         force_render, sim=sim, seed=seed)
+        if motion is None:
+            motion = np.loadtxt(cfg["motionToImitate"])  # ant_imitate.py:87-90
+        motion = np.ascontiguousarray(motion, dtype=np.float64)
+        if motion.ndim != 2 or motion.shape[1] != self.num_dof:
+            raise ValueError("the motion to imitate must be [frames, %d]" % self.num_dof)
+        self.motion_to_imitate = torch.from_numpy(motion).to(self.device)
+        self.target_pose_idx = torch.ones(self.num_envs, device=self.device, dtype=torch.long)
+        self._pose_diff = torch.zeros(self.num_envs, device=self.device, dtype=torch.float64)
+        self._qws = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=self.device)
+        self._group = process_group
+
+    def _imitate_args(self, n_total):
+        return ops.imitate_args(self.motion_to_imitate, self.target_pose_idx, self._pose_diff, self._qws,
+                                self.QUANTILE_THRESHOLD, self.DISTANCE_FLOOR, float(self.death_cost), n_total)
+
+    def post_physics_step(self):
+        world = distributed.world_size(self._group)
+        if world == 1:
+            ops.ant_imitate_step(self._params(), self._buffers(), self._imitate_args(self.num_envs), self.num_envs)
+        else:
+            counts = distributed.gather_records(torch.tensor([self.num_envs], device=self.device), self._group)
+            im = self._imitate_args(int(counts.sum()))
+            p, b = self._params(), self._buffers()
+            ops.ant_imitate_observe(p, b, im, self.num_envs)
+            ops.quantile_sharded(self._pose_diff, self.QUANTILE_THRESHOLD, im.n_total, self._qws,
+                                 lambda h: dist.all_reduce(h, group=self._group))
+            ops.ant_imitate_finish(p, b, im, self.num_envs)
+        self.extras["true_objective"] = self._true_objective
+
+    @property
+    def pose_threshold(self):
+        """max(1.8, quantile) of the last step (synchronises)."""
+        return max(self.DISTANCE_FLOOR, float(self._qws.view(torch.float64)[5]))

@@ -377,6 +377,94 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T):
     print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+def gen_ant_imitate(seed=41, N=257, T=7, F=9):
+    """AntImitate (tasks/ant_imitate.py): Ant observations + the pose-imitation reward with its
+    global quantile reset threshold (:447-555) and the target_pose_idx bookkeeping (:405-419)."""
+    import contextlib
+    import io
+    _install_gym_stubs()
+    mod = ref_shim.load("isaacgymenvs.tasks.ant_imitate")
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    cfg = _cfg("AntImitate")
+
+    class Fake(mod.AntImitate):
+        def __init__(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    t = Fake()
+    D, S = 8, 24
+    _loco_common(t, cfg, N, D, g, 0.55)
+    t.obs_buf = torch.zeros(N, 60)
+    lo, hi = t.dof_limits_lower, t.dof_limits_upper
+    # np.loadtxt gives float64: the reward arithmetic of the reference runs in double
+    motion = (lo.double() + (hi - lo).double() * torch.rand(F, D, generator=g, dtype=torch.float64)).numpy()
+    t.motion_to_imitate = torch.tensor(motion)
+    t.target_pose_idx = torch.ones(N, dtype=torch.long)
+    t.reset_buf = (torch.rand(N, generator=g) < 0.3).long()
+    keys = ["in_root", "in_dof_state", "in_sensors", "in_actions", "rand", "out_dof_state", "obs", "potentials",
+            "prev_potentials", "rew", "reset", "progress", "randomize", "target_pose_idx", "pose_diff", "threshold",
+            "in_reset"]
+    rec = {k: [] for k in keys}
+    init = {"reset0": t.reset_buf.numpy().copy(), "progress0": t.progress_buf.numpy().copy(),
+            "potentials0": t.potentials.numpy().copy(), "target_pose_idx0": t.target_pose_idx.numpy().copy(),
+            "initial_root_states": t.initial_root_states.numpy().copy(),
+            "initial_dof_pos": t.initial_dof_pos.numpy().copy(),
+            "dof_limits_lower": lo.numpy().copy(), "dof_limits_upper": hi.numpy().copy(), "motion": motion}
+    torch.manual_seed(seed + 100)
+    for step in range(T):
+        _loco_inputs(t, N, D, S, g, 0.55, 0.1, False)
+        if step in (2, 5):  # joints close to the target frame: the 0.99 quantile drops below the 1.8 floor
+            tgt = t.motion_to_imitate[(t.target_pose_idx + 1).clamp(max=F - 1)].float()
+            t.dof_state.view(N, D, 2)[..., 0] = tgt + 0.02 * torch.randn(N, D, generator=g)
+            t.reset_buf.zero_()  # no re-drawn joints in these steps
+        rec["in_reset"].append(t.reset_buf.numpy().copy())
+        rec["in_root"].append(t.root_states.numpy().copy())
+        rec["in_dof_state"].append(t.dof_state.numpy().copy())
+        rec["in_sensors"].append(t.vec_sensor_tensor.numpy().copy())
+        rec["in_actions"].append(t.actions.numpy().copy())
+        ids = t.reset_buf.nonzero(as_tuple=False).flatten()
+        st = torch.get_rng_state()
+        idx_used = (t.target_pose_idx + 1).clone()
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference prints from inside the jit function
+            t.post_physics_step()
+        dense = np.zeros((N, 2 * D), np.float32)
+        if len(ids) > 0:
+            up, uv = _replay_uniforms(st, [(len(ids), D), (len(ids), D)])
+            dense[ids.numpy(), :D] = up.numpy()
+            dense[ids.numpy(), D:] = uv.numpy()
+        rec["rand"].append(dense)
+        # the intermediate the reward function does not return, by its own expressions (:508-510, :529)
+        pose_scaled = tj.unscale(t.motion_to_imitate[idx_used], lo, hi)
+        pose_diff = torch.sum(torch.abs(t.obs_buf[:, 12:20] - pose_scaled), dim=-1)
+        thr = max(1.8, torch.quantile(pose_diff, 0.99))
+        rec["pose_diff"].append(pose_diff.numpy().copy())
+        rec["threshold"].append(np.float64(float(thr)))
+        rec["out_dof_state"].append(t.dof_state.numpy().copy())
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["potentials"].append(t.potentials.numpy().copy())
+        rec["prev_potentials"].append(t.prev_potentials.numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+        rec["randomize"].append(t.randomize_buf.numpy().copy())
+        rec["target_pose_idx"].append(t.target_pose_idx.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(init)
+    e = cfg["env"]
+    out["meta"] = _meta(task="AntImitate", N=N, T=T, F=F, seed=seed, num_dof=D, num_sensor_floats=S, dt=cfg["sim"]["dt"],
+                        dof_vel_scale=e["dofVelocityScale"], contact_force_scale=e["contactForceScale"],
+                        angular_velocity_scale=0.1, up_weight=e["upWeight"], heading_weight=e["headingWeight"],
+                        actions_cost_scale=e["actionsCost"], energy_cost_scale=e["energyCost"],
+                        joints_at_limit_cost_scale=e["jointsAtLimitCost"], termination_height=e["terminationHeight"],
+                        death_cost=e["deathCost"], max_episode_length=e["episodeLength"], quantile=0.99,
+                        distance_floor=1.8)
+    np.savez_compressed(os.path.join(OUT, "ant_imitate.npz"), **out)
+    print("ant_imitate.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+          "thresholds", out["threshold"], "resets", out["reset"].sum(1), "idx max", out["target_pose_idx"].max(1),
+          "success", [(out["rew"][i] == 6.0).sum() for i in range(T)])
+
+
 def gen_ant(seed=1, N=449, T=4):
     _gen_loco("ant", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, seed, N, T)
 
@@ -1026,7 +1114,7 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/igx.h"
@@ -321,7 +322,8 @@ int orc_loco_reset(const igx_loco_params *p, const igx_loco_buffers *b, const in
 /* tasks/ant.py:376-386, :339-366, :463-497, :414-460, :332-337 and
  * tasks/humanoid.py:398-407, :360-390, :489-524, :434-486.
  * humanoid != 0 selects the Humanoid observation layout and reward. */
-static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int humanoid)
+static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, int humanoid,
+                     const igx_imitate_args *im)
 {
     const int D = p->num_dof;
     const int S = p->num_sensor_floats;
@@ -425,7 +427,24 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
         float actions_cost = row_sum(tmp, D);
         float total;
         float progress_reward = pot - prev_pot;
-        if (!humanoid) {
+        if (im) { /* tasks/ant_imitate.py:405-419, :508-519 (fp64: the motion table promotes) */
+            int64_t idx = im->target_pose_idx[e] + 1;
+            im->target_pose_idx[e] = idx;
+            if (idx < 0) idx = 0;
+            if (idx >= im->num_frames) idx = im->num_frames - 1;
+            const double *m = im->motion + idx * D;
+            double diff[IGX_MAX_DOF];
+            for (int j = 0; j < D; ++j) {
+                double lo = (double)p->dof_limits_lower[j], hi = (double)p->dof_limits_upper[j];
+                double span = (double)(float)(p->dof_limits_upper[j] - p->dof_limits_lower[j]);
+                double scaled = (2.0 * m[j] - hi - lo) / span;
+                diff[j] = fabs((double)obs[12 + j] - scaled);
+            }
+            /* torch.sum over 8 doubles: 4 lanes over 2 blocks, lanes left to right */
+            double pose_diff = (((diff[0] + diff[4]) + (diff[1] + diff[5])) + (diff[2] + diff[6])) + (diff[3] + diff[7]);
+            im->pose_diff[e] = pose_diff;
+            total = (float)exp(-pose_diff);
+        } else if (!humanoid) {
             for (int j = 0; j < D; ++j) tmp[j] = fabsf(act[j] * obs[12 + D + j]);
             float electricity_cost = row_sum(tmp, D);
             int64_t cnt = 0;
@@ -446,7 +465,7 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
                   - p->actions_cost_scale * actions_cost - p->energy_cost_scale * electricity_cost
                   - dof_at_limit_cost;
         }
-        if (obs[0] < p->termination_height) total = p->death_cost;
+        if (obs[0] < p->termination_height) total = im ? (float)im->death_cost : p->death_cost;
         if (obs[0] < p->termination_height) rst = 1;
         if ((float)prog >= p->max_episode_length_m1) rst = 1;
 
@@ -460,12 +479,12 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
 
 int orc_ant_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n)
 {
-    return loco_step(p, b, n, 0);
+    return loco_step(p, b, n, 0, NULL);
 }
 
 int orc_humanoid_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n)
 {
-    return loco_step(p, b, n, 1);
+    return loco_step(p, b, n, 1, NULL);
 }
 
 /* ------------------------------------------- torch_jit_utils, batched --- */
@@ -1083,5 +1102,50 @@ int orc_episode_stats_step(const igx_episode_buffers *b, int64_t n, double out[3
         b->current_lengths[e] = cl * not_done;
     }
     out[0] = (double)cnt; out[1] = sr; out[2] = sl;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ AntImitate --- */
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* torch.quantile(x, q), 'linear': sort, ranks = q * (n - 1), lerp(below, above, frac) */
+double orc_quantile_f64(const double *x, int64_t n, double q)
+{
+    double *s = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(s, x, sizeof(double) * (size_t)n);
+    qsort(s, (size_t)n, sizeof(double), cmp_double);
+    double ranks = q * (double)(n - 1);
+    int64_t below = (int64_t)ranks, above = (int64_t)ceil(ranks);
+    double w = ranks - (double)below, a = s[below], b = s[above], diff = b - a;
+    free(s);
+    return (fabs(w) < 0.5) ? a + w * diff : b - diff * (1.0 - w); /* at::native::lerp */
+}
+
+int orc_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n)
+{
+    return loco_step(p, b, n, 0, im);
+}
+
+/* tasks/ant_imitate.py:523-555 given the global threshold */
+int orc_ant_imitate_finish(const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n, double quantile_value)
+{
+    double thr = im->distance_floor > quantile_value ? im->distance_floor : quantile_value;
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t idx = im->target_pose_idx[e];
+        if (im->pose_diff[e] > thr) {
+            b->reset[e] = 1;
+            b->rew[e] = (float)im->death_cost;
+            idx = 0;
+        }
+        if (idx >= im->num_frames - 3) {
+            b->rew[e] = (float)(-3.0 * im->death_cost);
+            idx = 0;
+        }
+        im->target_pose_idx[e] = idx;
+    }
     return 0;
 }

@@ -207,3 +207,38 @@ def episode_stats_step(bufs, n):
     out = (C.c_double * 3)()
     assert lib().orc_episode_stats_step(C.byref(b), C.c_int64(n), out) == 0
     return int(out[0]), float(out[1]), float(out[2])
+
+
+# ---- AntImitate ------------------------------------------------------------------
+def quantile_f64(x, q):
+    x = np.ascontiguousarray(x, np.float64)
+    fn = lib().orc_quantile_f64
+    fn.restype = C.c_double
+    return float(fn(C.c_void_p(x.ctypes.data), C.c_int64(x.size), C.c_double(q)))
+
+
+def imitate_args(arrays, num_frames, quantile, distance_floor, death_cost, n_total):
+    """igx_imitate_args over numpy arrays: motion [F,8] f64, target_pose_idx [n] i64, pose_diff [n] f64."""
+    im = _abi.ImitateArgs(num_frames=num_frames, quantile=quantile, distance_floor=distance_floor,
+                          death_cost=death_cost, n_total=n_total)
+    for k in ("motion", "target_pose_idx", "pose_diff"):
+        setattr(im, k, _np_ptr(arrays[k]))
+    return im
+
+
+def ant_imitate_observe(params, bufs, im, n):
+    b = _abi.make_buffers(_abi.LocoBuffers, bufs, _np_ptr)
+    assert lib().orc_ant_imitate_observe(C.byref(params), C.byref(b), C.byref(im), C.c_int64(n)) == 0
+
+
+def ant_imitate_finish(bufs, im, n, quantile_value):
+    b = _abi.make_buffers(_abi.LocoBuffers, bufs, _np_ptr)
+    assert lib().orc_ant_imitate_finish(C.byref(b), C.byref(im), C.c_int64(n), C.c_double(quantile_value)) == 0
+
+
+def ant_imitate_step(params, bufs, im, arrays, n):
+    """One GPU's worth: observe, global quantile, finish.  Returns the quantile value."""
+    ant_imitate_observe(params, bufs, im, n)
+    qv = quantile_f64(arrays["pose_diff"][:n], im.quantile)
+    ant_imitate_finish(bufs, im, n, qv)
+    return qv

@@ -336,3 +336,38 @@ def write_golden_motions(g, dirpath):
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return path
+
+
+def ant_imitate_replay(g, step_fn, to_buf, to_np, zeros):
+    """Replay ant_imitate.npz.  step_fn(params, bufs, arrays, meta) runs one post_physics_step on the
+    backend buffers (bufs: igx_loco_buffers names; arrays: motion / target_pose_idx / pose_diff)."""
+    m = g["meta"]
+    N, T = m["N"], m["T"]
+    p = loco_params(m, g)
+    progress, pot = to_buf(g["progress0"]), to_buf(g["potentials0"])
+    randomize = zeros((N,), np.int64)
+    arrays = dict(motion=to_buf(g["motion"]), target_pose_idx=to_buf(g["target_pose_idx0"]),
+                  pose_diff=zeros((N,), np.float64))
+    init_root, init_dof = to_buf(g["initial_root_states"]), to_buf(g["initial_dof_pos"])
+    nonangle = [c for c in range(60) if c not in LOCO_ANGLE_COLS]
+    for t in range(T):
+        ds = to_buf(g["in_dof_state"][t])
+        bufs = dict(root_states=to_buf(g["in_root"][t]), dof_state=ds, sensors=to_buf(g["in_sensors"][t]),
+                    actions=to_buf(g["in_actions"][t]), initial_root_states=init_root, initial_dof_pos=init_dof,
+                    rand=to_buf(g["rand"][t]), obs=zeros((N, 60), np.float32), potentials=pot,
+                    prev_potentials=zeros((N,), np.float32), up_vec=zeros((N, 3), np.float32),
+                    heading_vec=zeros((N, 3), np.float32), rew=zeros((N,), np.float32),
+                    reset=to_buf(g["in_reset"][t]), progress=progress, randomize=randomize)
+        qv = step_fn(p, bufs, arrays, m)
+        what = "step %d " % t
+        assert np.array_equal(to_np(arrays["pose_diff"]).view(np.uint64), g["pose_diff"][t].view(np.uint64)), what + "pose_diff"
+        assert max(m["distance_floor"], float(qv)) == float(g["threshold"][t]), what + "threshold"
+        for k, ref in (("reset", "reset"), ("progress", "progress"), ("randomize", "randomize")):
+            assert np.array_equal(to_np(bufs[k]), g[ref][t]), what + k
+        assert np.array_equal(to_np(arrays["target_pose_idx"]), g["target_pose_idx"][t]), what + "target_pose_idx"
+        obs = to_np(bufs["obs"])
+        assert bit_equal_fraction(obs[:, nonangle], g["obs"][t][:, nonangle]) == 1.0, what + "obs"
+        assert_angle_close(obs[:, list(LOCO_ANGLE_COLS)], g["obs"][t][:, list(LOCO_ANGLE_COLS)], what=what + "angles")
+        assert_close(to_np(bufs["rew"]), g["rew"][t], what=what + "rew")  # exp() in fp64, rounded to fp32
+        assert bit_equal_fraction(to_np(ds), g["out_dof_state"][t]) == 1.0, what + "dof_state"
+        assert bit_equal_fraction(to_np(pot), g["potentials"][t]) == 1.0, what + "potentials"

@@ -1,0 +1,102 @@
+"""AntImitate and the exact device quantile on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from isaacgym_amd import _abi, ops, synthetic
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _ws():
+    return torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 257, 4096, 100003, 1 << 20])
+@pytest.mark.parametrize("q", [0.0, 0.5, 0.99, 1.0])
+def test_quantile_equals_torch(n, q):
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.rand(n, generator=gen, device=DEV, dtype=torch.float64) * 12.0
+    if n > 4:
+        x[: n // 4] = x[0]          # many duplicates
+        x[-1] = -3.5                 # negative values and zeros order correctly too
+        x[-2] = 0.0
+    got = ops.quantile_f64(x, q)
+    assert float(got) == float(torch.quantile(x.cpu(), q)), (n, q)
+
+
+def test_quantile_sharded_equals_whole():
+    n = 300001
+    x = torch.rand(n, device=DEV, dtype=torch.float64) ** 3
+    shards = [x[:100000].contiguous(), x[100000:100007].contiguous(), x[100007:].contiguous()]
+    # emulate 3 ranks on one device: per-rank workspaces, "all-reduce" = sum of the three histograms
+    wss = [_ws() for _ in shards]
+    from isaacgym_amd import _lib
+    import ctypes as C
+    lib = _lib.lib()
+    st = _lib.current_stream(torch.device(DEV))
+    for ws in wss:
+        _lib.check(lib.igx_quantile_begin(_lib.tensor_ptr(ws), C.c_double(0.99), C.c_int64(n), st))
+    for p in range(_abi.IGX_QUANTILE_PASSES):
+        for ws, sh in zip(wss, shards):
+            _lib.check(lib.igx_quantile_histogram(_lib.tensor_ptr(sh), C.c_int64(sh.numel()), _lib.tensor_ptr(ws), C.c_int32(p), st))
+        total = sum(ws[8:8 + 4096] for ws in wss)
+        for ws in wss:
+            ws[8:8 + 4096] = total
+            _lib.check(lib.igx_quantile_advance(_lib.tensor_ptr(ws), C.c_int32(p), st))
+    want = float(torch.quantile(x.cpu(), 0.99))
+    for ws in wss:
+        assert float(ws.view(torch.float64)[5]) == want
+
+
+def test_ant_imitate_golden():
+    g = H.load_golden("ant_imitate")
+    ws = _ws()
+
+    def step(p, bufs, arrays, m):
+        im = ops.imitate_args(arrays["motion"], arrays["target_pose_idx"], arrays["pose_diff"], ws, m["quantile"],
+                              m["distance_floor"], m["death_cost"])
+        ops.ant_imitate_step(p, bufs, im, m["N"])
+        return float(ws.view(torch.float64)[5])
+
+    H.ant_imitate_replay(g, step, to_buf=dev, to_np=lambda t: t.cpu().numpy(),
+                         zeros=lambda shape, dt: torch.zeros(shape, device=DEV, dtype={np.int64: torch.int64,
+                                                                                      np.float64: torch.float64}.get(dt, torch.float32)))
+
+
+@pytest.mark.parametrize("n", [1, 67, 50001, 1 << 20])
+def test_ant_imitate_vs_oracle(n):
+    F = 40
+    p = synthetic.loco_params(synthetic.ANT, seed=3, rng_offset=1)
+    t = synthetic.loco_state(synthetic.ANT, n, 13, DEV, with_rand=True)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    lo, hi = synthetic.loco_limits(8)
+    lo, hi = torch.tensor(lo, device=DEV, dtype=torch.float64), torch.tensor(hi, device=DEV, dtype=torch.float64)
+    arrays = dict(motion=lo + (hi - lo) * torch.rand(F, 8, generator=gen, device=DEV, dtype=torch.float64),
+                  target_pose_idx=torch.randint(0, F - 1, (n,), generator=gen, device=DEV),
+                  pose_diff=torch.zeros(n, dtype=torch.float64, device=DEV))
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    ref_arrays = {k: v.cpu().numpy().copy() for k, v in arrays.items()}
+    ws = _ws()
+    for step in range(2):
+        p.rng_offset = 1 + step
+        im = ops.imitate_args(arrays["motion"], arrays["target_pose_idx"], arrays["pose_diff"], ws, 0.99, 1.8, -2.0)
+        ops.ant_imitate_step(p, t, im, n)
+        torch.cuda.synchronize()
+        oim = oracle.imitate_args(ref_arrays, F, 0.99, 1.8, -2.0, n)
+        qv = oracle.ant_imitate_step(p, ref, oim, ref_arrays, n)
+        assert float(ws.view(torch.float64)[5]) == qv
+        assert np.array_equal(arrays["pose_diff"].cpu().numpy().view(np.uint64), ref_arrays["pose_diff"].view(np.uint64))
+        assert np.array_equal(arrays["target_pose_idx"].cpu().numpy(), ref_arrays["target_pose_idx"])
+        for k in ("reset", "progress", "randomize"):
+            assert np.array_equal(t[k].cpu().numpy(), ref[k]), k
+        H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew")
+        for k in ("dof_state", "potentials", "prev_potentials"):
+            assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k

@@ -297,3 +297,37 @@ def test_amp_state_init_modes(motion_lib, state_init):
     assert torch.equal(task.obs_buf, task._amp_obs_buf[:, 0])
     task.step(torch.zeros(n, 28, device=DEV))
     assert int(task.progress_buf.min()) == 1
+
+
+# ------------------------------------------------------------------------- AntImitate
+def test_ant_imitate_class_golden():
+    g = H.load_golden("ant_imitate")
+    m = g["meta"]
+    N, T = m["N"], m["T"]
+    frames = [dict(root_states=g["in_root"][t], dof_state=g["in_dof_state"][t], sensors=g["in_sensors"][t])
+              for t in range(T)]
+    init = dict(root_states=g["in_root"][0], dof_state=g["in_dof_state"][0].reshape(N, 8, 2), sensors=g["in_sensors"][0])
+    sim = ReplaySim(N, DEV, init, frames, dict(dof_limits_lower=g["dof_limits_lower"].tolist(),
+                                               dof_limits_upper=g["dof_limits_upper"].tolist()))
+    task = tasks.AntImitate(C.task_config("AntImitate", N), DEV, DEV, sim=sim, motion=g["motion"])
+    assert torch.equal(task.target_pose_idx, torch.ones(N, dtype=torch.long, device=DEV))
+    task.initial_root_states.copy_(dev(g["initial_root_states"]))
+    task.initial_dof_pos.copy_(dev(g["initial_dof_pos"]))
+    task.progress_buf.copy_(dev(g["progress0"]))
+    task.potentials.copy_(dev(g["potentials0"]))
+    for t in range(T):
+        task.reset_buf.copy_(dev(g["in_reset"][t]))
+        task.reset_rand = dev(g["rand"][t])
+        _, rew, reset, _ = task.step(dev(g["in_actions"][t]))
+        assert task.pose_threshold == float(g["threshold"][t])
+        assert np.array_equal(host(reset), g["reset"][t]) and np.array_equal(host(task.progress_buf), g["progress"][t])
+        assert np.array_equal(host(task.target_pose_idx), g["target_pose_idx"][t])
+        H.assert_close(host(rew), g["rew"][t], what="rew")
+
+
+def test_make_ant_imitate_runs():
+    task = tasks.make("AntImitate", 5000, DEV, seed=2)
+    task.reset_done()
+    for _ in range(3):
+        task.step(torch.zeros(5000, 8, device=DEV))
+    assert task.pose_threshold >= 1.8 and int(task.progress_buf.max()) == 3
