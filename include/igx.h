@@ -198,6 +198,58 @@ int igx_quantile_advance(void *workspace, int32_t pass, igx_stream_t stream);
 int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * HumanoidImitate (tasks/humanoid_imitate.py): 63-dof / 22-body humanoid.
+ * post_physics_step (:634-643): progress / randomize += 1, flagged resets
+ * (reset_idx :579-605, as Humanoid), observations (:795-831)
+ *   obs[205] = [unscale(dof_pos) 63 | dof_vel * dofVelocityScale 63 | root row 13 | body positions 22 x 3],
+ * reward (:672-758) against one frame of the motion file (fp64 where the
+ * fp64 motion table enters):
+ *   exp(-0.2 sum|body_pos - target_pos|) + exp(-0.3 sum|obs[0:63] - unscale(target_pose)|)
+ *   + exp(-0.05 sum|obs[63:126]|) + (root_z > termination_height ? up_weight : 0)
+ *   + 0.1 exp(-|root_xy|) - actions_cost_scale * sum(a^2);
+ * reset on root_z < termination_height, x^2 + y^2 > termination_radius^2, or time-out.
+ * ---------------------------------------------------------------------- */
+#define IGX_HIM_DOF 63
+#define IGX_HIM_BODIES 22
+#define IGX_HIM_OBS 205
+
+typedef struct igx_humanoid_imitate_params {
+    float dt;
+    float dof_vel_scale;
+    float up_weight;
+    float actions_cost_scale;
+    float termination_height;
+    float termination_radius_sq;  /* float32(termination_radius ** 2) */
+    float max_episode_length_m1;
+    int32_t reserved;
+    float targets[3];
+    float reserved2;
+    float dof_limits_lower[IGX_HIM_DOF + 1];
+    float dof_limits_upper[IGX_HIM_DOF + 1];
+    uint64_t seed;
+    uint64_t rng_offset;
+} igx_humanoid_imitate_params;
+
+typedef struct igx_humanoid_imitate_buffers {
+    const float *root_states;          /* [N,13] */
+    float *dof_state;                  /* [N,63,2] */
+    const float *rigid_body_states;    /* [N,22,13] */
+    const float *actions;              /* [N,63] */
+    const float *initial_root_states;  /* [N,13] */
+    const float *initial_dof_pos;      /* [N,63] */
+    const float *rand;                 /* [N,126] or NULL (in-kernel Philox) */
+    const double *motion_frame;        /* [63 + 22*13] fp64: the frame to imitate (motion_to_imitate[41]) */
+    float *obs;                        /* [N,205] */
+    float *potentials;                 /* [N] written for reset envs only */
+    float *prev_potentials;            /* [N] " */
+    float *rew;                        /* [N] */
+    int64_t *reset, *progress, *randomize; /* [N]; randomize may be NULL */
+} igx_humanoid_imitate_buffers;
+
+int igx_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_humanoid_imitate_buffers *b,
+                              int64_t n_envs, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * AllegroHand in-hand reorientation.
  * Two entry points, as the reference splits the work (tasks/allegro_hand.py):
  *  igx_allegro_pre_physics  = pre_physics_step :586-615 with reset_target_pose

@@ -36,6 +36,7 @@ SYMBOLS = {
 SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])
 SYMBOLS.update({
+    "igx_humanoid_imitate_step": _STEP_SIG,
     "igx_ant_imitate_step": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "igx_ant_imitate_observe": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "igx_ant_imitate_finish": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
@@ -123,7 +124,7 @@ def tensor_ptr(t, dtype=None):
 _I64_FIELDS = {"reset", "progress", "randomize", "reset_goal", "terminate", "motion_ids", "frame_idx0",
                "frame_idx1", "object_indices", "goal_object_indices", "env_ids", "done"}
 _RAW_FIELDS = {"workspace"}  # opaque device scratch: any dtype
-_F64_FIELDS = {"motion_times"}
+_F64_FIELDS = {"motion_times", "motion_frame"}
 
 
 def _ptr_checked(name):

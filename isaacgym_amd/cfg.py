@@ -36,6 +36,13 @@ _TASKS = {
                  terminationHeight=0.8, plane=dict(staticFriction=1.0, dynamicFriction=1.0, restitution=0.0),
                  enableCameraSensors=False),
         sim=_SIM, task=dict(randomize=False, randomization_params={})),
+    "HumanoidImitate": dict(
+        env=dict(numEnvs=4096, envSpacing=5, episodeLength=1000, enableDebugVis=False, clipActions=1.0, powerScale=1.0,
+                 headingWeight=0.5, upWeight=0.1, actionsCost=0.01, energyCost=0.05, dofVelocityScale=0.1,
+                 angularVelocityScale=0.25, contactForceScale=0.01, jointsAtLimitCost=0.25, deathCost=-1.0,
+                 terminationHeight=0.5, terminationRadius=1.0,
+                 plane=dict(staticFriction=1.0, dynamicFriction=1.0, restitution=0.0), enableCameraSensors=False),
+        sim=_SIM, task=dict(randomize=False, randomization_params={})),
     "AllegroHand": dict(
         env=dict(numEnvs=16384, envSpacing=0.75, episodeLength=600, enableDebugVis=False, aggregateMode=1,
                  clipObservations=5.0, clipActions=1.0, stiffnessScale=1.0, forceLimitScale=1.0,

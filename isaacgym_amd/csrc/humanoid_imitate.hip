@@ -1,0 +1,252 @@
+// Fused post_physics_step of HumanoidImitate (63 dofs, 22 bodies, 205-wide observation).
+//
+// A wavefront owns a tile of 16 consecutive environments (13 KB of observation rows in
+// LDS; a 64-row tile would be 52 KB): the tile's contiguous slices of dof_state, root
+// rows, rigid-body rows and actions are streamed with coalesced 16-byte non-temporal
+// loads and scattered to their observation columns in LDS; flagged environments are
+// reset by the whole wave (lane j = joint j); four lanes share an environment for the
+// reward sums (fp64 where the fp64 motion frame enters, as in the reference); the rows
+// leave as one contiguous slab.
+//
+// Reference: IsaacGymEnvs/isaacgymenvs/tasks/humanoid_imitate.py:634-643, :579-605,
+// :795-831, :672-758; utils/torch_jit_utils.py:670-681.
+#include "igx_device.hpp"
+#include "igx_host.hpp"
+#include "igx_tile.hpp"
+
+namespace igx {
+
+constexpr int HD = IGX_HIM_DOF, HB = IGX_HIM_BODIES, HO = IGX_HIM_OBS;
+constexpr int HT = 16;             // rows per tile
+constexpr int BODY_ROW = HB * 13;  // 286
+constexpr int C_VEL = HD, C_ROOT = 2 * HD, C_BODY = 2 * HD + 13;
+
+__global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humanoid_imitate_params p,
+                                                                const igx_humanoid_imitate_buffers b, int64_t n)
+{
+    __shared__ __align__(16) float s_tile[HT * HO];
+    __shared__ __align__(16) float s_act[HT * HD];
+    __shared__ double s_tgt[HD + HB * 3];  // unscaled target pose, target body positions
+    __shared__ float s_lim[2 * HD + 2];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * HT;
+    const int nvalid = (n - base >= HT) ? HT : (int)(n - base);
+    const bool full = nvalid == HT;
+
+    // ---- loads, issued back to back
+    constexpr int DOF4 = HT * HD * 2 / 4, ROOT4 = HT * 13 / 4, BODY4 = HT * BODY_ROW / 4, ACT4 = HT * HD / 4;
+    v4f r_dof[(DOF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE], r_body[(BODY4 + WAVE - 1) / WAVE],
+        r_act[(ACT4 + WAVE - 1) / WAVE];
+    const int64_t ef = base + (lane < nvalid ? lane : 0);  // lanes 0..15 carry the per-env scalars
+    int64_t prog = ld_stream(b.progress + ef);
+    int64_t rst = ld_stream(b.reset + ef);
+    int64_t rnd = ld_stream((b.randomize ? b.randomize : b.progress) + ef);
+    if (full) {
+        load_chunks<DOF4>(b.dof_state + base * (2 * HD), r_dof, lane);
+        load_chunks<ROOT4>(b.root_states + base * 13, r_root, lane);
+        load_chunks<BODY4>(b.rigid_body_states + base * BODY_ROW, r_body, lane);
+        load_chunks<ACT4>(b.actions + base * HD, r_act, lane);
+    }
+
+    // ---- per-block constants
+    if (lane < HD) {
+        s_lim[lane] = p.dof_limits_lower[lane];
+        s_lim[HD + 1 + lane] = p.dof_limits_upper[lane];
+    }
+    wave_sync();
+    for (int i = lane; i < HD + HB * 3; i += WAVE) {
+        if (i < HD) {  // unscale(pose, lower, upper): fp64 numerator, fp32 (upper - lower) widened
+            const double lo = (double)s_lim[i], hi = (double)s_lim[HD + 1 + i];
+            const double span = (double)(s_lim[HD + 1 + i] - s_lim[i]);
+            s_tgt[i] = (2.0 * b.motion_frame[i] - hi - lo) / span;
+        } else {
+            const int k = i - HD, body = k / 3, c = k - 3 * body;
+            s_tgt[i] = b.motion_frame[HD + body * 13 + c];
+        }
+    }
+
+    // ---- stage: every input element to its observation column
+    if (full) {
+#pragma unroll
+        for (int it = 0; it < (DOF4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= DOF4 || k < DOF4) {
+                const float pos[2] = {r_dof[it].x, r_dof[it].z}, vel[2] = {r_dof[it].y, r_dof[it].w};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pr = 2 * k + h, env = pr / HD, j = pr - env * HD;
+                    s_tile[env * HO + j] = unscale(pos[h], s_lim[j], s_lim[HD + 1 + j]);
+                    s_tile[env * HO + C_VEL + j] = vel[h] * p.dof_vel_scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < (ROOT4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if (k < ROOT4) {
+                const float x[4] = {r_root[it].x, r_root[it].y, r_root[it].z, r_root[it].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = 4 * k + i, env = f / 13, c = f - env * 13;
+                    s_tile[env * HO + C_ROOT + c] = x[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < (BODY4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= BODY4 || k < BODY4) {
+                const float x[4] = {r_body[it].x, r_body[it].y, r_body[it].z, r_body[it].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = 4 * k + i, env = f / BODY_ROW, w = f - env * BODY_ROW, body = w / 13, c = w - body * 13;
+                    if (c < 3) s_tile[env * HO + C_BODY + body * 3 + c] = x[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < (ACT4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= ACT4 || k < ACT4) *reinterpret_cast<v4f *>(s_act + 4 * k) = r_act[it];
+        }
+    } else {
+        for (int i = lane; i < nvalid * HD; i += WAVE) {
+            const int env = i / HD, j = i - env * HD;
+            const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * HD + i];
+            s_tile[env * HO + j] = unscale(pv.x, s_lim[j], s_lim[HD + 1 + j]);
+            s_tile[env * HO + C_VEL + j] = pv.y * p.dof_vel_scale;
+            s_act[i] = b.actions[base * HD + i];
+        }
+        for (int i = lane; i < nvalid * 13; i += WAVE) {
+            const int env = i / 13, c = i - env * 13;
+            s_tile[env * HO + C_ROOT + c] = b.root_states[base * 13 + i];
+        }
+        for (int i = lane; i < nvalid * HB * 3; i += WAVE) {
+            const int env = i / (HB * 3), k = i - env * (HB * 3), body = k / 3, c = k - 3 * body;
+            s_tile[env * HO + C_BODY + k] = b.rigid_body_states[(base + env) * BODY_ROW + body * 13 + c];
+        }
+    }
+    wave_sync();
+
+    // ---- resets (tasks/humanoid_imitate.py:579-605): one flagged environment at a time, lane j = joint j
+    uint64_t reset_mask = __ballot(lane < nvalid && rst != 0);
+    while (reset_mask) {
+        const int src = __builtin_ctzll(reset_mask);
+        reset_mask &= reset_mask - 1;
+        const int64_t e = base + src;
+        if (lane < HD) {
+            const int j = lane;
+            float up, uv;
+            if (b.rand) {
+                up = b.rand[e * (2 * HD) + j];
+                uv = b.rand[e * (2 * HD) + HD + j];
+            } else {
+                float q[4];
+                philox_uniform4(p.seed, p.rng_offset, e, j >> 2, q);
+                const int a = j & 3;
+                up = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
+                philox_uniform4(p.seed, p.rng_offset, e, (HD + j) >> 2, q);
+                const int c = (HD + j) & 3;
+                uv = c == 0 ? q[0] : c == 1 ? q[1] : c == 2 ? q[2] : q[3];
+            }
+            const float dp = 0.4f * up + (-0.2f), dv = 0.2f * uv + (-0.1f);
+            const float lo = s_lim[j], hi = s_lim[HD + 1 + j];
+            const float np_ = tensor_clamp(b.initial_dof_pos[e * HD + j] + dp, lo, hi);
+            reinterpret_cast<v2f *>(b.dof_state + e * (2 * HD))[j] = v2f{np_, dv};
+            s_tile[src * HO + j] = unscale(np_, lo, hi);
+            s_tile[src * HO + C_VEL + j] = dv * p.dof_vel_scale;
+        } else {  // lane 63: the per-env scalars of reset_idx
+            const float *ir = b.initial_root_states + e * 13;
+            const float pot = -norm3(f3{p.targets[0] - ir[0], p.targets[1] - ir[1], 0.0f}) / p.dt;
+            b.potentials[e] = pot;
+            b.prev_potentials[e] = pot;
+        }
+    }
+    wave_sync();
+
+    // ---- reward: four lanes per environment, strided partial sums, then a 4-lane butterfly
+    {
+        const int env = lane >> 2, part = lane & 3;
+        const float *row = s_tile + env * HO;
+        double pose = 0.0, body = 0.0;
+        float vel = 0.0f, act = 0.0f;
+        if (env < nvalid) {
+            for (int j = part; j < HD; j += 4) {
+                pose += fabs((double)row[j] - s_tgt[j]);
+                vel += fabsf(row[C_VEL + j]);
+                const float a = s_act[env * HD + j];
+                act += a * a;
+            }
+            for (int k = part; k < HB * 3; k += 4) body += fabs((double)row[C_BODY + k] - s_tgt[HD + k]);
+        }
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {
+            pose += __shfl_xor(pose, off);
+            body += __shfl_xor(body, off);
+            vel += __shfl_xor(vel, off);
+            act += __shfl_xor(act, off);
+        }
+        // the environment's flags live in lane `env`
+        const int64_t prog_e = __shfl(prog, env), rst_e = __shfl(rst, env), rnd_e = __shfl(rnd, env);
+        if (part == 0 && env < nvalid) {
+            const int64_t e = base + env;
+            const float x = row[C_ROOT], y = row[C_ROOT + 1], z = row[C_ROOT + 2];
+            const double reward_body = exp(-0.2 * body);
+            const double reward_pose = exp(-0.3 * pose);
+            const float reward_velocity = expf(-0.05f * vel);
+            const double reward_up = (z - p.termination_height > 0.0f) ? (double)p.up_weight : 0.0;
+            const float reward_centered = expf(-sqrtf(x * x + y * y));
+            double total = 0.0;  // total_reward += term, in the reference's order
+            total += reward_body;
+            total += reward_pose;
+            total += (double)reward_velocity;
+            total += reward_up;
+            total += (double)(0.1f * reward_centered);
+            total += (double)(-(p.actions_cost_scale * act));
+            int64_t prog2 = prog_e + 1, rst2 = rst_e;
+            if (rst_e != 0) { prog2 = 0; rst2 = 0; }
+            if (z < p.termination_height) rst2 = 1;
+            if (x * x + y * y > p.termination_radius_sq) rst2 = 1;
+            if ((float)prog2 >= p.max_episode_length_m1) rst2 = 1;
+            st_stream(b.rew + e, (float)total);
+            st_stream(b.reset + e, rst2);
+            st_stream(b.progress + e, prog2);
+            if (b.randomize) st_stream(b.randomize + e, rnd_e + 1);
+        }
+    }
+
+    // ---- observation rows out as one contiguous slab
+    if (full && dev_aligned16(b.obs)) {
+        constexpr int N4 = HT * HO / 4;
+        v4f *o4 = reinterpret_cast<v4f *>(b.obs + base * HO);
+#pragma unroll
+        for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= N4 || k < N4) st_stream(o4 + k, *reinterpret_cast<const v4f *>(s_tile + 4 * k));
+        }
+    } else {
+        for (int i = lane; i < nvalid * HO; i += WAVE) b.obs[base * HO + i] = s_tile[i];
+    }
+}
+
+}  // namespace igx
+
+using namespace igx;
+
+extern "C" int igx_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_humanoid_imitate_buffers *b,
+                                         int64_t n, igx_stream_t stream)
+{
+    const char *who = "igx_humanoid_imitate_step";
+    if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
+    if (n < 0 || n > ((int64_t)1 << 34)) return fail(IGX_E_SIZE, "%s: n_envs %lld out of range", who, (long long)n);
+    if (n == 0) return IGX_OK;
+    if (!b->root_states || !b->dof_state || !b->rigid_body_states || !b->actions || !b->initial_root_states ||
+        !b->initial_dof_pos || !b->motion_frame || !b->obs || !b->potentials || !b->prev_potentials || !b->rew ||
+        !b->reset || !b->progress)
+        return fail(IGX_E_NULL, "%s: a required buffer is NULL", who);
+    if (!aligned16(b->root_states) || !aligned16(b->dof_state) || !aligned16(b->rigid_body_states) || !aligned16(b->actions))
+        return fail(IGX_E_ALIGN, "%s: input tensors must be 16-byte aligned", who);
+    hipLaunchKernelGGL(humanoid_imitate_kernel, dim3((unsigned)((n + HT - 1) / HT)), dim3(WAVE), 0,
+                       static_cast<hipStream_t>(stream), *p, *b, n);
+    return launch_status(who);
+}

@@ -34,6 +34,10 @@ def humanoid_reset(params, tensors, env_ids):
     _lib.call_reset("igx_humanoid_reset", params, _abi.LocoBuffers, tensors, env_ids)
 
 
+def humanoid_imitate_step(params, tensors, n_envs):
+    _lib.call_step("igx_humanoid_imitate_step", params, _abi.HumanoidImitateBuffers, tensors, n_envs)
+
+
 def allegro_pre_physics(params, tensors, n_envs):
     _lib.call_step("igx_allegro_pre_physics", params, _abi.AllegroBuffers, tensors, n_envs)
 

@@ -57,6 +57,7 @@ _PHYSICS_OWNED = {
     "Ant": ("root_states", "dof_state", "sensors"),
     "AntImitate": ("root_states", "dof_state", "sensors"),
     "Humanoid": ("root_states", "dof_state", "sensors", "dof_force"),
+    "HumanoidImitate": ("root_states", "dof_state", "rigid_body_states"),
     "AllegroHand": ("dof_state", "dof_force", "root_state_tensor"),
     "HumanoidAMP": ("root_states", "dof_state", "rigid_body_state", "contact_forces"),
 }
@@ -69,6 +70,8 @@ def _draw(task, n, seed, device, **kw):
         return synthetic.loco_state(synthetic.ANT, n, seed, device)
     if task == "Humanoid":
         return synthetic.loco_state(synthetic.HUMANOID, n, seed, device)
+    if task == "HumanoidImitate":
+        return synthetic.him_state(n, seed, device)
     if task == "AllegroHand":
         return synthetic.allegro_state(n, seed, device, kw.get("obs_type", "full_state"))
     if task == "HumanoidAMP":
@@ -96,6 +99,9 @@ class SyntheticSim(TensorSim):
             p = synthetic.loco_params(spec)
             self.asset = dict(dof_limits_lower=lo, dof_limits_upper=hi,
                               motor_efforts=list(p.motor_efforts)[:spec["num_dof"]], num_dof=spec["num_dof"])
+        elif task == "HumanoidImitate":
+            lo, hi = synthetic.him_limits()
+            self.asset = dict(dof_limits_lower=lo, dof_limits_upper=hi, num_dof=_abi.IGX_HIM_DOF)
         elif task == "AllegroHand":
             p = synthetic.allegro_params()
             self.asset = dict(dof_limits_lower=list(p.dof_lower), dof_limits_upper=list(p.dof_upper),

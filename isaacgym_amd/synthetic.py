@@ -240,3 +240,52 @@ def amp_state(n, seed, device, num_amp_obs_steps=2, max_episode_length=300):
         reset=torch.zeros(n, dtype=torch.int64, device=device),
         terminate=torch.zeros(n, dtype=torch.int64, device=device),
         progress=torch.randint(0, max_episode_length + 1, (n,), generator=gen, device=device))
+
+
+# ---------------------------------------------------------------- HumanoidImitate
+def him_limits():
+    D = _abi.IGX_HIM_DOF
+    return [-1.0 - 0.01 * (j % 21) for j in range(D)], [1.0 + 0.02 * (j % 21) for j in range(D)]
+
+
+def him_params(seed=0, rng_offset=0, termination_radius=1.0):
+    lo, hi = him_limits()
+    return _abi.HumanoidImitateParams(
+        dt=0.0166, dof_vel_scale=0.1, up_weight=0.1, actions_cost_scale=0.01, termination_height=0.5,
+        termination_radius_sq=float(torch.tensor(termination_radius ** 2, dtype=torch.float32)),
+        max_episode_length_m1=999.0, targets=[1000.0, 0.0, 0.0], dof_limits_lower=lo, dof_limits_upper=hi,
+        seed=seed, rng_offset=rng_offset)
+
+
+def him_state(n, seed, device, with_rand=False):
+    """name->tensor dict of igx_humanoid_imitate_buffers: ~12 % of roots outside the unit circle,
+    a few % below the termination height."""
+    D, NB, NO = _abi.IGX_HIM_DOF, _abi.IGX_HIM_BODIES, _abi.IGX_HIM_OBS
+    gen = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=gen, device=device)  # noqa: E731
+    lo, hi = (torch.tensor(v, device=device) for v in him_limits())
+    root = torch.empty(n, 13, device=device)
+    root[:, 0:2] = r(n, 2) * 0.5
+    root[:, 2] = 0.9 + r(n) * 0.2
+    root[:, 3:7] = _quats(n, gen, device)
+    root[:, 7:13] = r(n, 6)
+    dof_state = torch.empty(n, D, 2, device=device)
+    dof_state[..., 0] = lo + (hi - lo) * (torch.rand(n, D, generator=gen, device=device) * 1.04 - 0.02)
+    dof_state[..., 1] = r(n, D)
+    init_root = torch.zeros(n, 13, device=device)
+    init_root[:, 0:2] = r(n, 2) * 0.05
+    init_root[:, 2] = 0.9
+    init_root[:, 6] = 1.0
+    frame = torch.cat([(lo + (hi - lo) * torch.rand(D, generator=gen, device=device)).double(),
+                       (r(NB * 13) * 0.5).double()])
+    t = dict(root_states=root, dof_state=dof_state, rigid_body_states=r(n, NB, 13) * 0.5,
+             actions=torch.rand(n, D, generator=gen, device=device) * 2 - 1, initial_root_states=init_root,
+             initial_dof_pos=torch.zeros(n, D, device=device), motion_frame=frame.contiguous(),
+             obs=torch.zeros(n, NO, device=device), potentials=torch.full((n,), -1000.0 / 0.0166, device=device),
+             prev_potentials=torch.full((n,), -1000.0 / 0.0166, device=device), rew=torch.zeros(n, device=device),
+             reset=(torch.rand(n, generator=gen, device=device) < 0.02).to(torch.int64),
+             progress=torch.randint(0, 1000, (n,), generator=gen, device=device),
+             randomize=torch.zeros(n, dtype=torch.int64, device=device))
+    if with_rand:
+        t["rand"] = torch.rand(n, 2 * D, generator=gen, device=device)
+    return t

@@ -6,6 +6,7 @@ from .cartpole import Cartpole
 from .cartpole_sample import CartpoleSample
 from .humanoid import Humanoid
 from .humanoid_amp import HumanoidAMP
+from .humanoid_imitate import HumanoidImitate
 
 isaacgym_task_map = {
     "AllegroHand": AllegroHand,
@@ -15,6 +16,7 @@ isaacgym_task_map = {
     "CartpoleSample": CartpoleSample,
     "Humanoid": Humanoid,
     "HumanoidAMP": HumanoidAMP,
+    "HumanoidImitate": HumanoidImitate,
 }
 
 
@@ -31,6 +33,9 @@ def make(name, num_envs, device="cuda:0", seed=0, sim=None, **env_overrides):
             extra["num_amp_obs_steps"] = cfg["env"]["numAMPObsSteps"]
         sim = SyntheticSim(name, num_envs, device, seed=seed, **extra)
     kw = {} if name == "HumanoidAMP" else dict(seed=seed)
+    if name == "HumanoidImitate" and "motionToImitate" not in cfg:
+        import numpy as np
+        kw["motion"] = np.random.default_rng(seed).standard_normal((48, 63 + 22 * 13)) * 0.5
     if name == "AntImitate" and "motionToImitate" not in cfg:
         import numpy as np
         from .. import synthetic

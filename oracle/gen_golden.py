@@ -465,6 +465,101 @@ def gen_ant_imitate(seed=41, N=257, T=7, F=9):
           "success", [(out["rew"][i] == 6.0).sum() for i in range(T)])
 
 
+def gen_humanoid_imitate(seed=51, N=67, T=4, F=48):
+    """HumanoidImitate (tasks/humanoid_imitate.py): 63-dof humanoid, 205-wide observation (:795-831), pose /
+    rigid-body tracking reward against frame 41 of the motion file (:672-758).
+    Run with PYTORCH_JIT=0: extract_positions_from_rigid_body_states (utils/torch_jit_utils.py:670-681) builds its
+    index tensor on "cuda:0"; un-scripted, that one allocation can be redirected to the CPU while every other line
+    of the reference runs as written."""
+    import contextlib
+    import io
+    assert os.environ.get("PYTORCH_JIT") == "0", "run as: PYTORCH_JIT=0 python oracle/gen_golden.py humanoid_imitate"
+    _install_gym_stubs()
+    mod = ref_shim.load("isaacgymenvs.tasks.humanoid_imitate")
+    cfg = _cfg("HumanoidImitate")
+
+    class Fake(mod.HumanoidImitate):
+        def __init__(self):
+            pass
+
+    real_empty = torch.empty
+
+    def cpu_empty(*a, **k):
+        if str(k.get("device", "")) == "cuda:0":
+            k["device"] = "cpu"
+        return real_empty(*a, **k)
+
+    g = torch.Generator().manual_seed(seed)
+    t = Fake()
+    D, S, NBODY = 63, 12, 22
+    _loco_common(t, cfg, N, D, g, 0.9)
+    e = cfg["env"]
+    t.termination_radius = e["terminationRadius"]
+    t.angular_velocity_scale = e.get("angularVelocityScale", 0.1)
+    t.obs_buf = torch.zeros(N, 205)
+    efforts = (torch.rand(D, generator=g) * 180 + 20).tolist()
+    t.max_motor_effort = max(efforts)
+    t.motor_efforts = torch.tensor(efforts)
+    t.control_steps, t.debug_viz_rigid_bodies = 0, False
+    lo, hi = t.dof_limits_lower, t.dof_limits_upper
+    motion = np.concatenate([(lo.double() + (hi - lo).double() * torch.rand(F, D, generator=g, dtype=torch.float64)).numpy(),
+                             torch.randn(F, NBODY * 13, generator=g, dtype=torch.float64).numpy() * 0.5], axis=1)
+    t.motion_to_imitate = torch.tensor(motion)
+    t.rigid_body_states = torch.zeros(N, NBODY * 13)
+    t.reset_buf = (torch.rand(N, generator=g) < 0.3).long()
+    t.progress_buf[:4] = torch.tensor([997, 998, 999, 5])
+    keys = ["in_root", "in_dof_state", "in_rigid_body_states", "in_actions", "rand", "out_dof_state", "obs",
+            "potentials", "prev_potentials", "rew", "reset", "progress", "randomize"]
+    rec = {k: [] for k in keys}
+    init = {"reset0": t.reset_buf.numpy().copy(), "progress0": t.progress_buf.numpy().copy(),
+            "potentials0": t.potentials.numpy().copy(), "initial_root_states": t.initial_root_states.numpy().copy(),
+            "initial_dof_pos": t.initial_dof_pos.numpy().copy(), "dof_limits_lower": lo.numpy().copy(),
+            "dof_limits_upper": hi.numpy().copy(), "motor_efforts": t.motor_efforts.numpy().copy(), "motion": motion}
+    torch.manual_seed(seed + 100)
+    for step in range(T):
+        _loco_inputs(t, N, D, S, g, 0.9, 0.4, False)
+        t.root_states[:, 0:2] = torch.randn(N, 2, generator=g) * 0.6   # some leave the termination radius
+        t.root_states[5, 0:2] = torch.tensor([1.0, 0.0])               # exactly on the radius: not > r^2
+        if step == 2:  # joints near the target frame: large pose reward
+            t.dof_state.view(N, D, 2)[..., 0] = t.motion_to_imitate[41, :D].float() + 0.01 * torch.randn(N, D, generator=g)
+        t.rigid_body_states.copy_(torch.randn(N, NBODY * 13, generator=g) * 0.5)
+        rec["in_root"].append(t.root_states.numpy().copy())
+        rec["in_dof_state"].append(t.dof_state.numpy().copy())
+        rec["in_rigid_body_states"].append(t.rigid_body_states.numpy().copy())
+        rec["in_actions"].append(t.actions.numpy().copy())
+        ids = t.reset_buf.nonzero(as_tuple=False).flatten()
+        st = torch.get_rng_state()
+        torch.empty = cpu_empty
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                t.post_physics_step()
+        finally:
+            torch.empty = real_empty
+        dense = np.zeros((N, 2 * D), np.float32)
+        if len(ids) > 0:
+            up, uv = _replay_uniforms(st, [(len(ids), D), (len(ids), D)])
+            dense[ids.numpy(), :D] = up.numpy()
+            dense[ids.numpy(), D:] = uv.numpy()
+        rec["rand"].append(dense)
+        rec["out_dof_state"].append(t.dof_state.numpy().copy())
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["potentials"].append(t.potentials.numpy().copy())
+        rec["prev_potentials"].append(t.prev_potentials.numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+        rec["randomize"].append(t.randomize_buf.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(init)
+    out["meta"] = _meta(task="HumanoidImitate", N=N, T=T, F=F, seed=seed, num_dof=D, num_bodies=NBODY, dt=cfg["sim"]["dt"],
+                        dof_vel_scale=e["dofVelocityScale"], up_weight=e["upWeight"], actions_cost_scale=e["actionsCost"],
+                        termination_height=e["terminationHeight"], termination_radius=e["terminationRadius"],
+                        max_episode_length=e["episodeLength"], max_motor_effort=t.max_motor_effort, pose_frame=41)
+    np.savez_compressed(os.path.join(OUT, "humanoid_imitate.npz"), **out)
+    print("humanoid_imitate.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+          "resets", out["reset"].sum(1), "rew", out["rew"].mean(1))
+
+
 def gen_ant(seed=1, N=449, T=4):
     _gen_loco("ant", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, seed, N, T)
 
@@ -1114,10 +1209,10 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    names = sys.argv[1:] or list(GENERATORS)
+    names = sys.argv[1:] or [n for n in GENERATORS if n != "humanoid_imitate"]  # that one needs PYTORCH_JIT=0
     for n in names:
         GENERATORS[n]()

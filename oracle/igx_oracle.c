@@ -1149,3 +1149,75 @@ int orc_ant_imitate_finish(const igx_loco_buffers *b, const igx_imitate_args *im
     }
     return 0;
 }
+
+/* ------------------------------------------------------------- HumanoidImitate --- */
+/* tasks/humanoid_imitate.py:634-643 (post_physics_step), :579-605 (reset_idx), :795-831
+ * (observations), :672-758 (reward; fp64 where the fp64 motion frame enters).  The 63- and
+ * 66-term sums are sequential here; the reward is compared at 1e-5, the flags exactly. */
+int orc_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_humanoid_imitate_buffers *b, int64_t n)
+{
+    const int D = IGX_HIM_DOF, NB = IGX_HIM_BODIES, NO = IGX_HIM_OBS;
+    double tgt_pose[IGX_HIM_DOF], tgt_pos[IGX_HIM_BODIES * 3];
+    for (int j = 0; j < D; ++j) {
+        double lo = (double)p->dof_limits_lower[j], hi = (double)p->dof_limits_upper[j];
+        double span = (double)(float)(p->dof_limits_upper[j] - p->dof_limits_lower[j]);
+        tgt_pose[j] = (2.0 * b->motion_frame[j] - hi - lo) / span;
+    }
+    for (int k = 0; k < NB * 3; ++k) tgt_pos[k] = b->motion_frame[D + (k / 3) * 13 + k % 3];
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        float *ds = b->dof_state + e * D * 2;
+        float *obs = b->obs + e * NO;
+        int64_t prog = b->progress[e] + 1;
+        int64_t rst = b->reset[e];
+        if (b->randomize) b->randomize[e] += 1;
+        if (rst != 0) {
+            for (int j = 0; j < D; ++j) {
+                float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset);
+                float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset);
+                float t = b->initial_dof_pos[e * D + j] + (0.4f * up + (-0.2f));
+                t = fminf(t, p->dof_limits_upper[j]);
+                t = fmaxf(t, p->dof_limits_lower[j]);
+                ds[2 * j] = t;
+                ds[2 * j + 1] = 0.2f * uv + (-0.1f);
+            }
+            const float *ir = b->initial_root_states + e * 13;
+            float tt[3] = { p->targets[0] - ir[0], p->targets[1] - ir[1], 0.0f };
+            float pot = -norm3(tt) / p->dt;
+            b->potentials[e] = pot;
+            b->prev_potentials[e] = pot;
+            prog = 0;
+            rst = 0;
+        }
+        for (int j = 0; j < D; ++j) {
+            obs[j] = unscale1(ds[2 * j], p->dof_limits_lower[j], p->dof_limits_upper[j]);
+            obs[D + j] = ds[2 * j + 1] * p->dof_vel_scale;
+        }
+        for (int c = 0; c < 13; ++c) obs[2 * D + c] = b->root_states[e * 13 + c];
+        for (int k = 0; k < NB * 3; ++k) obs[2 * D + 13 + k] = b->rigid_body_states[(e * NB + k / 3) * 13 + k % 3];
+
+        double pose = 0.0, body = 0.0;
+        float vel = 0.0f, act = 0.0f;
+        for (int j = 0; j < D; ++j) {
+            pose += fabs((double)obs[j] - tgt_pose[j]);
+            vel += fabsf(obs[D + j]);
+            act += b->actions[e * D + j] * b->actions[e * D + j];
+        }
+        for (int k = 0; k < NB * 3; ++k) body += fabs((double)obs[2 * D + 13 + k] - tgt_pos[k]);
+        float x = obs[126], y = obs[127], z = obs[128];
+        double total = 0.0;
+        total += exp(-0.2 * body);
+        total += exp(-0.3 * pose);
+        total += (double)expf(-0.05f * vel);
+        total += (z - p->termination_height > 0.0f) ? (double)p->up_weight : 0.0;
+        total += (double)(0.1f * expf(-sqrtf(x * x + y * y)));
+        total += (double)(-(p->actions_cost_scale * act));
+        if (z < p->termination_height) rst = 1;
+        if (x * x + y * y > p->termination_radius_sq) rst = 1;
+        if ((float)prog >= p->max_episode_length_m1) rst = 1;
+        b->rew[e] = (float)total;
+        b->reset[e] = rst;
+        b->progress[e] = prog;
+    }
+    return 0;
+}

@@ -84,6 +84,10 @@ def loco_reset(params, bufs, env_ids):
     _reset(lib().orc_loco_reset, params, _abi.LocoBuffers, bufs, env_ids)
 
 
+def humanoid_imitate_step(params, bufs, n):
+    _call(lib().orc_humanoid_imitate_step, params, _abi.HumanoidImitateBuffers, bufs, n)
+
+
 def allegro_pre_physics(params, bufs, n):
     _call(lib().orc_allegro_pre_physics, params, _abi.AllegroBuffers, bufs, n)
 

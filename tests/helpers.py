@@ -371,3 +371,42 @@ def ant_imitate_replay(g, step_fn, to_buf, to_np, zeros):
         assert_close(to_np(bufs["rew"]), g["rew"][t], what=what + "rew")  # exp() in fp64, rounded to fp32
         assert bit_equal_fraction(to_np(ds), g["out_dof_state"][t]) == 1.0, what + "dof_state"
         assert bit_equal_fraction(to_np(pot), g["potentials"][t]) == 1.0, what + "potentials"
+
+
+def him_params(meta, g, seed=0, rng_offset=0):
+    return _abi.HumanoidImitateParams(
+        dt=meta["dt"], dof_vel_scale=meta["dof_vel_scale"], up_weight=meta["up_weight"],
+        actions_cost_scale=meta["actions_cost_scale"], termination_height=meta["termination_height"],
+        termination_radius_sq=float(np.float32(meta["termination_radius"] ** 2)),
+        max_episode_length_m1=float(meta["max_episode_length"] - 1), targets=[1000.0, 0.0, 0.0],
+        dof_limits_lower=g["dof_limits_lower"], dof_limits_upper=g["dof_limits_upper"], seed=seed, rng_offset=rng_offset)
+
+
+def him_replay(g, step_fn, to_buf, to_np, zeros):
+    """Replay humanoid_imitate.npz through step_fn(params, bufs, n)."""
+    m = g["meta"]
+    N, T, D = m["N"], m["T"], m["num_dof"]
+    p = him_params(m, g)
+    reset, progress = to_buf(g["reset0"]), to_buf(g["progress0"])
+    pot, prev = to_buf(g["potentials0"]), to_buf(g["potentials0"])
+    randomize = zeros((N,), np.int64)
+    frame = to_buf(np.ascontiguousarray(g["motion"][m["pose_frame"]]))
+    init_root, init_dof = to_buf(g["initial_root_states"]), to_buf(g["initial_dof_pos"])
+    for t in range(T):
+        ds = to_buf(g["in_dof_state"][t].reshape(N, D, 2))
+        bufs = dict(root_states=to_buf(g["in_root"][t]), dof_state=ds,
+                    rigid_body_states=to_buf(g["in_rigid_body_states"][t].reshape(N, 22, 13)),
+                    actions=to_buf(g["in_actions"][t]), initial_root_states=init_root, initial_dof_pos=init_dof,
+                    rand=to_buf(g["rand"][t]), motion_frame=frame, obs=zeros((N, 205), np.float32), potentials=pot,
+                    prev_potentials=prev, rew=zeros((N,), np.float32), reset=reset, progress=progress,
+                    randomize=randomize)
+        step_fn(p, bufs, N)
+        what = "step %d " % t
+        for k in ("reset", "progress", "randomize"):
+            assert np.array_equal(to_np(bufs[k]), g[k][t]), what + k
+        # observations are copies and elementwise IEEE arithmetic: exact
+        assert bit_equal_fraction(to_np(bufs["obs"]), g["obs"][t]) == 1.0, what + "obs"
+        assert bit_equal_fraction(to_np(ds).reshape(-1, 2), g["out_dof_state"][t]) == 1.0, what + "dof_state"
+        assert bit_equal_fraction(to_np(pot), g["potentials"][t]) == 1.0, what + "potentials"
+        assert bit_equal_fraction(to_np(prev), g["prev_potentials"][t]) == 1.0, what + "prev_potentials"
+        assert_close(to_np(bufs["rew"]), g["rew"][t], what=what + "rew")  # sums of 63 / 66 terms, exp

@@ -73,6 +73,33 @@ def main():
             sets = [synthetic.amp_state(n, s, DEV, K) for s in range(2)]
             report("amp_step_K%d" % K, timed(lambda i: ops.humanoid_amp_step(p, sets[i % 2], n), a.steps), BYTES["amp"])
             del sets
+    if on("him"):
+        p = synthetic.him_params(1, 0)
+        m = min(n, 1 << 19)
+        sets = [synthetic.him_state(m, s, DEV) for s in range(2)]
+        # read dof 504 + root 52 + body positions 264 + actions 252 + flags 16; write obs 820 + rew 4 + flags 16
+        report("humanoid_imitate", timed(lambda i: ops.humanoid_imitate_step(p, sets[i % 2], m), a.steps), 1928, m)
+        del sets
+    if on("ant_imitate"):
+        from isaacgym_amd import _abi
+        p = synthetic.loco_params(synthetic.ANT, 1, 0)
+        sets = [synthetic.loco_state(synthetic.ANT, n, s, DEV) for s in range(3)]
+        lo, hi = (torch.tensor(v, device=DEV, dtype=torch.float64) for v in synthetic.loco_limits(8))
+        motion = lo + (hi - lo) * torch.rand(64, 8, device=DEV, dtype=torch.float64)
+        idx = torch.randint(0, 60, (n,), device=DEV)
+        pd = torch.zeros(n, dtype=torch.float64, device=DEV)
+        ws = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+        im = ops.imitate_args(motion, idx, pd, ws, 0.99, 1.8, -2.0)
+        report("ant_imitate_step(total)", timed(lambda i: ops.ant_imitate_step(p, sets[i % 3], im, n), a.steps), 556 + 32)
+        report("ant_imitate_observe", timed(lambda i: ops.ant_imitate_observe(p, sets[i % 3], im, n), a.steps), 556 + 24)
+        report("quantile_f64", timed(lambda i: ops.quantile_f64(pd, 0.99, ws), a.steps), 8 * 6)
+        del sets
+    if on("episode"):
+        from isaacgym_amd.episode_stats import EpisodeStats
+        es = EpisodeStats(n, DEV)
+        rew = torch.randn(n, device=DEV)
+        done = (torch.rand(n, device=DEV) < 0.01).to(torch.int64)
+        report("episode_stats", timed(lambda i: es.step(rew, done), a.steps), 4 + 8 + 16)
     if on("tail"):
         obs = torch.randn(n, 60, device=DEV)
         out = torch.empty_like(obs)
