@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--task", default="ant", choices=["ant", "humanoid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1,
+                    help="rehearsal only: put every rank on this device index instead of LOCAL_RANK")
     ap.add_argument("--episode-stats", action="store_true",
                     help="also run the episode-statistics kernel every step (inside the timed region) and "
                          "all-gather the totals over the ranks afterwards")
@@ -99,10 +103,14 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.all_ranks_on_device < 0 else args.all_ranks_on_device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     spec = synthetic.ANT if args.task == "ant" else synthetic.HUMANOID
     step = ops.ant_step if args.task == "ant" else ops.humanoid_step
@@ -147,7 +155,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per launch on the launch stream
 
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
