@@ -436,6 +436,72 @@ int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, co
                            const igx_motion_state_out *state, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Observation / action noise of the domain-randomisation block
+ * (tasks/base/vec_task.py:693-703 gaussian, :720-729 uniform noise_lambda):
+ *   noise = ((corr * corr_scale + corr_shift) + fresh * scale) + shift
+ *   out   = x + noise (additive)  or  x * noise (scaling)
+ * one fp32 rounding per operation.  gaussian: corr_scale = var_corr, corr_shift =
+ * mu_corr, scale = var, shift = mu; uniform: corr_scale = hi_corr - lo_corr,
+ * corr_shift = lo_corr, scale = hi - lo, shift = lo (differences taken in double,
+ * then rounded to fp32, as the reference's Python floats are).  `corr` is the
+ * draw the reference keeps in params['corr'] from the first call on (always
+ * standard normal, :697 / :724); `fresh` is this call's randn_like / rand_like.
+ * With fresh == NULL the kernel draws it itself (Philox4x32-10 keyed by seed,
+ * counter = (element index / 4, offset); Box-Muller for the gaussian), which
+ * saves writing and re-reading one tensor per step; the stream then differs
+ * from torch's, the distribution does not.  corr == NULL switches the noise off.
+ * ---------------------------------------------------------------------- */
+#define IGX_NOISE_ADDITIVE 0
+#define IGX_NOISE_SCALING 1
+#define IGX_NOISE_GAUSSIAN 0
+#define IGX_NOISE_UNIFORM 1
+typedef struct igx_noise {
+    const float *corr;     /* [count] or NULL = no noise */
+    const float *fresh;    /* [count] or NULL = drawn in the kernel */
+    float corr_scale, corr_shift, scale, shift;
+    int32_t operation;     /* IGX_NOISE_ADDITIVE / IGX_NOISE_SCALING */
+    int32_t distribution;  /* IGX_NOISE_GAUSSIAN / IGX_NOISE_UNIFORM; read only when fresh == NULL */
+    uint64_t seed;
+    uint64_t offset;       /* advance by one per call */
+} igx_noise;
+
+/* out = noise_lambda(x) on count floats; out may alias x. */
+int igx_noise_apply(const igx_noise *nz, const float *x, float *out, int64_t count, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * What happens to the actions between VecTask.step's entry and the physics step:
+ * action noise (tasks/base/vec_task.py:381-382), torch.clamp(+-clip_actions)
+ * (:384), the copy into self.actions and the task's scaling into joint forces
+ * or PD targets, one launch.
+ *   IGX_ACT_FORCE     targets = (a * gain[j]) * power_scale
+ *                     (tasks/ant.py:369-370 joint_gears, tasks/humanoid.py:393-394 and
+ *                     tasks/amp/humanoid_amp_base.py:418 motor_efforts)
+ *   IGX_ACT_PD_TARGET targets = offset[j] + gain[j] * a
+ *                     (tasks/amp/humanoid_amp_base.py:413, :467-469 _action_to_pd_targets)
+ *   IGX_ACT_FIRST_DOF targets[i, 0] = a[i] * power_scale, targets[i, 1:] = 0; num_actions 1
+ *                     (tasks/cartpole.py:164-166, power_scale = max_push_effort)
+ * ---------------------------------------------------------------------- */
+#define IGX_ACT_FORCE 0
+#define IGX_ACT_PD_TARGET 1
+#define IGX_ACT_FIRST_DOF 2
+typedef struct igx_action_stage {
+    const float *actions;      /* [N,num_actions] as handed to step() */
+    float *actions_out;        /* [N,num_actions] self.actions (after noise and clamp); NULL skips */
+    float *targets;            /* [N,num_actions]; IGX_ACT_FIRST_DOF: [N,num_dof] */
+    const float *gain;         /* [num_actions]; unused by IGX_ACT_FIRST_DOF */
+    const float *offset;       /* [num_actions], IGX_ACT_PD_TARGET only */
+    igx_noise noise;           /* over the N*num_actions actions */
+    float clip_actions;        /* env.clipActions; +inf copies */
+    float power_scale;
+    int32_t mode;
+    int32_t num_actions;
+    int32_t num_dof;           /* IGX_ACT_FIRST_DOF: dofs per env */
+    int32_t reserved;
+} igx_action_stage;
+
+int igx_action_stage_step(const igx_action_stage *s, int64_t n_envs, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * The part of VecTask.step every task shares (tasks/base/vec_task.py:401-418).
  * ---------------------------------------------------------------------- */
 typedef struct igx_vec_task_tail {
@@ -451,6 +517,9 @@ typedef struct igx_vec_task_tail {
     double max_episode_length_m1;
     float clip_obs;            /* env.clipObservations; +inf copies */
     int32_t reserved;
+    float *obs_noised;         /* [N,num_obs] obs_buf after observation noise (:407-408), may be obs_buf
+                                  itself (the reference rebinds self.obs_buf to it); NULL keeps no copy */
+    igx_noise obs_noise;       /* applied before the clamp; corr == NULL: none */
 } igx_vec_task_tail;
 
 int igx_vec_task_tail_step(const igx_vec_task_tail *t, int64_t n_envs, igx_stream_t stream);

@@ -141,11 +141,29 @@ class AmpBuffers(_Struct):
                 ("progress", ptr)]
 
 
+IGX_NOISE_ADDITIVE, IGX_NOISE_SCALING = 0, 1
+IGX_NOISE_GAUSSIAN, IGX_NOISE_UNIFORM = 0, 1
+IGX_ACT_FORCE, IGX_ACT_PD_TARGET, IGX_ACT_FIRST_DOF = 0, 1, 2
+
+
+class Noise(_Struct):
+    _fields_ = [("corr", ptr), ("fresh", ptr),
+                ("corr_scale", f32), ("corr_shift", f32), ("scale", f32), ("shift", f32),
+                ("operation", i32), ("distribution", i32), ("seed", u64), ("offset", u64)]
+
+
+class ActionStage(_Struct):
+    _fields_ = [("actions", ptr), ("actions_out", ptr), ("targets", ptr), ("gain", ptr), ("offset", ptr),
+                ("noise", Noise), ("clip_actions", f32), ("power_scale", f32),
+                ("mode", i32), ("num_actions", i32), ("num_dof", i32), ("reserved", i32)]
+
+
 class VecTaskTail(_Struct):
     _fields_ = [("obs_buf", ptr), ("obs_out", ptr), ("obs_count", i64),
                 ("states_buf", ptr), ("states_out", ptr), ("states_count", i64),
                 ("progress", ptr), ("reset", ptr), ("time_outs", ptr),
-                ("max_episode_length_m1", C.c_double), ("clip_obs", f32), ("reserved", i32)]
+                ("max_episode_length_m1", C.c_double), ("clip_obs", f32), ("reserved", i32),
+                ("obs_noised", ptr), ("obs_noise", Noise)]
 
 
 IGX_HIM_DOF, IGX_HIM_BODIES, IGX_HIM_OBS = 63, 22, 205

@@ -35,6 +35,8 @@ SYMBOLS = {
 }
 SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])
+SYMBOLS["igx_noise_apply"] = (C.c_int, [_P, _P, _P, C.c_int64, _P])
+SYMBOLS["igx_action_stage_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS.update({
     "igx_humanoid_imitate_step": _STEP_SIG,
     "igx_ant_imitate_step": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

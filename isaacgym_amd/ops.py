@@ -129,16 +129,103 @@ def humanoid_amp_reset(params, tensors, env_ids, state):
 
 
 # ---- VecTask.step tail --------------------------------------------------------
+class NoiseSpec:
+    """One entry of VecTask.dr_randomizations as the kernels take it (igx_noise):
+    noise = ((corr * corr_scale + corr_shift) + fresh * scale) + shift, added to or
+    multiplied with the tensor.  `corr` is the persistent standard-normal draw; the
+    per-call draw is either handed in (`fresh=`) or made in the kernel from
+    (seed, offset), offset advancing by one per use."""
+
+    def __init__(self, corr, corr_scale, corr_shift, scale, shift, operation="additive", distribution="gaussian", seed=0):
+        if operation not in ("additive", "scaling"):
+            raise ValueError("operation must be 'additive' or 'scaling', got %r" % (operation,))
+        if distribution not in ("gaussian", "uniform"):
+            raise ValueError("distribution must be 'gaussian' or 'uniform', got %r" % (distribution,))
+        self.corr = corr
+        self.corr_scale, self.corr_shift, self.scale, self.shift = corr_scale, corr_shift, scale, shift
+        self.operation, self.distribution = operation, distribution
+        self.seed, self.offset = int(seed), 0
+
+    def struct(self, count, fresh=None):
+        if self.corr.numel() != count or (fresh is not None and fresh.numel() != count):
+            raise ValueError("noise tensors must have %d elements" % count)
+        nz = _abi.Noise(corr=_lib.tensor_ptr(self.corr, torch.float32),
+                        fresh=_lib.tensor_ptr(fresh, torch.float32) if fresh is not None else None,
+                        corr_scale=self.corr_scale, corr_shift=self.corr_shift, scale=self.scale, shift=self.shift,
+                        operation=_abi.IGX_NOISE_SCALING if self.operation == "scaling" else _abi.IGX_NOISE_ADDITIVE,
+                        distribution=_abi.IGX_NOISE_UNIFORM if self.distribution == "uniform" else _abi.IGX_NOISE_GAUSSIAN,
+                        seed=self.seed, offset=self.offset)
+        if fresh is None:
+            self.offset += 1
+        return nz
+
+
+def noise_apply(spec, x, out=None, fresh=None):
+    """out = noise_lambda(x) (tasks/base/vec_task.py:693-701, :720-727)."""
+    dev = x.device
+    out = torch.empty_like(x) if out is None else out
+    nz = spec.struct(x.numel(), fresh)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_noise_apply(C.byref(nz), _lib.tensor_ptr(x, torch.float32), _lib.tensor_ptr(out, torch.float32),
+                                        C.c_int64(x.numel()), _lib.current_stream(dev))
+    _lib.check(rc)
+    return out
+
+
+def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0, clip_actions=float("inf"),
+                 actions_out=None, noise=None, fresh=None, num_dof=0):
+    """Noise, clamp, copy and scaling of the actions in one launch (igx_action_stage_step).
+    mode: "force" (a * gain * power_scale), "pd_target" (offset + gain * a) or
+    "first_dof" (targets[i, 0] = a[i] * power_scale, targets [N, num_dof])."""
+    f = torch.float32
+    dev = actions.device
+    modes = {"force": _abi.IGX_ACT_FORCE, "pd_target": _abi.IGX_ACT_PD_TARGET, "first_dof": _abi.IGX_ACT_FIRST_DOF}
+    if mode not in modes:
+        raise ValueError("mode must be one of %s" % sorted(modes))
+    if mode == "first_dof":
+        n, a = actions.numel(), 1
+        if targets.numel() != n * num_dof:
+            raise ValueError("targets must hold num_envs * num_dof floats")
+    else:
+        a = gain.numel()
+        n = actions.numel() // a
+        if n * a != actions.numel() or targets.numel() != actions.numel():
+            raise ValueError("actions and targets must be [N, %d]" % a)
+        if mode == "pd_target" and (offset is None or offset.numel() != a):
+            raise ValueError("pd_target mode needs an offset per action")
+    if actions_out is not None and actions_out.numel() != actions.numel():
+        raise ValueError("actions_out must have as many elements as actions")
+    s = _abi.ActionStage(actions=_lib.tensor_ptr(actions, f), targets=_lib.tensor_ptr(targets, f),
+                         actions_out=_lib.tensor_ptr(actions_out, f) if actions_out is not None else None,
+                         gain=_lib.tensor_ptr(gain, f) if gain is not None else None,
+                         offset=_lib.tensor_ptr(offset, f) if offset is not None else None,
+                         clip_actions=float(clip_actions), power_scale=float(power_scale), mode=modes[mode],
+                         num_actions=a, num_dof=int(num_dof))
+    if noise is not None:
+        s.noise = noise.struct(actions.numel(), fresh)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_action_stage_step(C.byref(s), C.c_int64(n), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_episode_length, states_buf=None,
-                  states_out=None):
+                  states_out=None, noise=None, fresh=None, obs_noised=None):
     """obs_out = clamp(obs_buf, +-clip_obs); states likewise; time_outs (torch.bool) =
-    (progress >= max_episode_length - 1) & (reset != 0)."""
+    (progress >= max_episode_length - 1) & (reset != 0).  With `noise` (a NoiseSpec) the
+    observation noise is applied before the clamp and the noised buffer kept in
+    `obs_noised` (may be obs_buf itself)."""
     f = torch.float32
     dev = obs_buf.device
     t = _abi.VecTaskTail()
     t.obs_buf, t.obs_out, t.obs_count = _lib.tensor_ptr(obs_buf, f), _lib.tensor_ptr(obs_out, f), obs_buf.numel()
     if obs_out.numel() != obs_buf.numel():
         raise ValueError("obs_out must have as many elements as obs_buf")
+    if noise is not None:
+        t.obs_noise = noise.struct(obs_buf.numel(), fresh)
+        if obs_noised is not None:
+            if obs_noised.numel() != obs_buf.numel():
+                raise ValueError("obs_noised must have as many elements as obs_buf")
+            t.obs_noised = _lib.tensor_ptr(obs_noised, f)
     if states_buf is not None and states_buf.numel():
         if states_out is None or states_out.numel() != states_buf.numel():
             raise ValueError("states_out must have as many elements as states_buf")

@@ -9,20 +9,26 @@ reference's task objects keeps working.  What differs:
 
 * physics is a `sim` object handed to the constructor (isaacgym_amd.sim), not
   an isaacgym handle; viewer, cameras and domain randomisation of simulation
-  parameters have no counterpart here;
-* the action clamp, the time-out flags and the clamped observation copy of
-  `step` are HIP kernels (igx_clamp, igx_vec_task_tail_step) writing into
-  persistent tensors: the returned observation tensor is overwritten by the
-  next `step` / `reset` call, where the reference returns a fresh tensor.
+  parameters have no counterpart here (`apply_randomizations` covers the
+  observation / action noise, :630-729);
+* the action noise and clamp, the time-out flags, the observation noise and the
+  clamped observation copy of `step` are HIP kernels (igx_action_stage_step /
+  igx_clamp, igx_vec_task_tail_step) writing into persistent tensors: the
+  returned observation tensor is overwritten by the next `step` / `reset` call,
+  where the reference returns a fresh tensor.  The per-call noise draw is made
+  inside the kernels (Philox), not by torch.randn_like.
 """
 import numpy as np
 import torch
 
-from ... import ops
+from ... import ops, randomization
 
 
 class VecTask:
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 24}
+    # True for tasks whose pre_physics_step goes through _scale_actions: step() then leaves the
+    # action noise and clamp to that same launch
+    FUSED_ACTION_STAGE = False
 
     def __init__(self, config, rl_device, sim_device, graphics_device_id=0, headless=True,
                  virtual_screen_capture=False, force_render=False, sim=None):
@@ -56,6 +62,13 @@ class VecTask:
         self.dt = config["sim"]["dt"]
         self.dr_randomizations = {}
         self.first_randomization = True
+        self.last_step = -1
+        self.last_rand_step = -1
+        self.noise_seed = int(config.get("seed", 0) or 0)
+        # recorded draws to use instead of the generators, for reproducing a torch run:
+        # {"actions": [fresh per step, ...], "actions_corr": [corr per re-randomisation, ...], "observations": ...}
+        self.replay_noise = None
+        self._stage = None
 
         self.sim = sim
         if sim.num_envs != self.num_environments:
@@ -132,15 +145,90 @@ class VecTask:
     def reset_idx(self, env_ids):
         pass
 
+    # ---- observation / action noise (vec_task.py:630-729) ------------------------
+    def apply_randomizations(self, dr_params):
+        """The non-physical part of the reference's method: when to re-randomise, the
+        randomize_buf bookkeeping, and the parameters of the two noise lambdas."""
+        rand_freq = dr_params.get("frequency", 1)
+        self.last_step = self.sim.num_simulate_calls
+        if self.first_randomization:
+            do_nonenv_randomize = True
+        else:
+            do_nonenv_randomize = (self.last_step - self.last_rand_step) >= rand_freq
+            rand_envs = torch.logical_and(self.randomize_buf >= rand_freq, self.reset_buf)
+            self.randomize_buf[rand_envs] = 0
+        if do_nonenv_randomize:
+            self.last_rand_step = self.last_step
+        made = []
+        for name in randomization.NONPHYSICAL:
+            if name in dr_params and do_nonenv_randomize:
+                entry = randomization.noise_params(dr_params[name], self.last_step)
+                # a fresh dict: the correlated draw of the previous one is dropped, as at :703 / :729
+                entry["noise_lambda"] = self._make_noise_lambda(name)
+                self.dr_randomizations[name] = entry
+                made.append(entry)
+        randomization.bind_operations(made)
+        self.first_randomization = False
+
+    def _noise_spec(self, name, like):
+        """The NoiseSpec of dr_randomizations[name]; its correlated draw is made at first use (:695-698)."""
+        entry = self.dr_randomizations[name]
+        spec = entry.get("spec")
+        if spec is None or spec.corr.numel() != like.numel():
+            cs, csh, sc, sh = randomization.noise_coefficients(entry)
+            corr = self._replayed(name + "_corr")
+            if corr is None:
+                corr = torch.randn_like(like, dtype=torch.float32)
+            spec = ops.NoiseSpec(corr, cs, csh, sc, sh, entry["operation"],
+                                 entry["distribution"], seed=(self.noise_seed << 1) | (name == "actions"))
+            spec.offset = self.control_steps << 1
+            entry["spec"] = spec
+            entry["corr"] = spec.corr
+        return spec
+
+    def _replayed(self, key):
+        queue = self.replay_noise.get(key) if self.replay_noise else None
+        return queue.pop(0).to(self.device, torch.float32).contiguous() if queue else None
+
+    def _make_noise_lambda(self, name):
+        def noise_lambda(tensor):
+            x = tensor.to(self.device, torch.float32).contiguous()
+            return ops.noise_apply(self._noise_spec(name, x), x, fresh=self._replayed(name))
+        return noise_lambda
+
+    def _noise_stage(self, name, like):
+        """noise= / fresh= keyword arguments for the kernels, empty without that randomisation."""
+        if not self.dr_randomizations.get(name, None):
+            return {}
+        return dict(noise=self._noise_spec(name, like), fresh=self._replayed(name))
+
     # ---- stepping (vec_task.py:370-418) ------------------------------------------
+    def _stage_actions(self, actions):
+        """Noise (:381-382) and clamp (:384) of the actions into self._action_tensor."""
+        stage = self._noise_stage("actions", actions)
+        if stage:
+            actions = ops.noise_apply(stage["noise"], actions, fresh=stage["fresh"])
+        ops.clamp(actions, -self.clip_actions, self.clip_actions, self._action_tensor)
+        return self._action_tensor
+
+    def _scale_actions(self, actions, targets, mode, gain=None, offset=None, power_scale=1.0, num_dof=0, keep=None):
+        """pre_physics_step of the tasks that only scale their actions: copy into `keep`
+        (self.actions) and scaling into `targets` in one launch, which also carries the action
+        noise and clamp when the call comes from step()."""
+        stage, self._stage = (self._stage or {}), None
+        actions = actions.to(self.device, torch.float32).contiguous()
+        ops.action_stage(actions, targets, mode, gain=gain, offset=offset, power_scale=power_scale, num_dof=num_dof,
+                         actions_out=keep, **stage)
+
     def step(self, actions):
-        if self.dr_randomizations.get("actions", None):
-            actions = self.dr_randomizations["actions"]["noise_lambda"](actions)
         actions = actions.to(self.device, torch.float32).contiguous()
         if actions.numel() != self._action_tensor.numel():
             raise ValueError("expected %d x %d actions, got %s" % (self.num_envs, self.num_actions, tuple(actions.shape)))
-        ops.clamp(actions, -self.clip_actions, self.clip_actions, self._action_tensor)
-        self.pre_physics_step(self._action_tensor)
+        if self.FUSED_ACTION_STAGE:
+            self._stage = dict(clip_actions=self.clip_actions, **self._noise_stage("actions", actions))
+            self.pre_physics_step(actions)
+        else:
+            self.pre_physics_step(self._stage_actions(actions))
 
         for _ in range(self.control_freq_inv):
             self.sim.simulate()
@@ -148,12 +236,12 @@ class VecTask:
         self.post_physics_step()
         self.control_steps += 1
 
-        if self.dr_randomizations.get("observations", None):
-            self.obs_buf = self.dr_randomizations["observations"]["noise_lambda"](self.obs_buf).contiguous()
+        stage = self._noise_stage("observations", self.obs_buf)
         ops.vec_task_tail(self.obs_buf, self._obs_out, self.clip_obs, self.progress_buf, self.reset_buf,
                           self._time_outs, self.max_episode_length,
                           self.states_buf if self.num_states > 0 else None,
-                          self._states_out if self.num_states > 0 else None)
+                          self._states_out if self.num_states > 0 else None,
+                          obs_noised=self.obs_buf if stage else None, **stage)
         self.timeout_buf = self._time_outs
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.obs_dict["obs"] = self._obs_out.to(self.rl_device)

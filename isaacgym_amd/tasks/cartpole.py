@@ -39,10 +39,13 @@ class Cartpole(VecTask):
         return dict(dof_state=self.dof_state, rand=self.reset_rand, obs=self.obs_buf, rew=self.rew_buf,
                     reset=self.reset_buf, progress=self.progress_buf)
 
+    FUSED_ACTION_STAGE = True
+
     def pre_physics_step(self, actions):  # cartpole.py:164-168
-        forces = torch.zeros(self.num_envs * self.num_dof, device=self.device, dtype=torch.float)
-        forces[::self.num_dof] = actions.to(self.device).squeeze() * self.max_push_effort
-        self.sim.apply_dof_forces(forces)
+        if not hasattr(self, "_forces"):
+            self._forces = torch.zeros(self.num_envs * self.num_dof, device=self.device, dtype=torch.float)
+        self._scale_actions(actions, self._forces, "first_dof", power_scale=self.max_push_effort, num_dof=self.num_dof)
+        self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
         ops.cartpole_step(self._params(), self._buffers(), self.num_envs)

@@ -72,6 +72,7 @@ class HumanoidAMPBase(VecTask):
         if len(self._contact_bodies) > 4:
             raise ValueError("at most 4 contact bodies")
         self.actions = torch.zeros(n, NUM_ACTIONS, device=dev)
+        self._targets = torch.zeros(n, NUM_ACTIONS, device=dev)
         asset = self.sim.asset
         if "dof_limits_lower" in asset:
             self.dof_limits_lower = torch.tensor(asset["dof_limits_lower"], device=dev, dtype=torch.float)
@@ -112,12 +113,17 @@ class HumanoidAMPBase(VecTask):
     def _action_to_pd_targets(self, action):  # :467-469
         return self._pd_action_offset + self._pd_action_scale * action
 
+    FUSED_ACTION_STAGE = True
+
     def pre_physics_step(self, actions):  # :410-422
-        self.actions = actions.to(self.device).clone()
         if self._pd_control:
-            self.sim.apply_dof_position_targets(self._action_to_pd_targets(self.actions))
+            self._scale_actions(actions, self._targets, "pd_target", gain=self._pd_action_scale,
+                                offset=self._pd_action_offset, keep=self.actions)
+            self.sim.apply_dof_position_targets(self._targets)
         else:
-            self.sim.apply_dof_forces(self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale)
+            self._scale_actions(actions, self._targets, "force", gain=self.motor_efforts, power_scale=self.power_scale,
+                                keep=self.actions)
+            self.sim.apply_dof_forces(self._targets)
 
     def _refresh_sim_tensors(self):
         self.sim.refresh()

@@ -56,6 +56,7 @@ class HumanoidImitate(VecTask):
         self.potentials = torch.tensor([-1000.0 / self.dt], device=dev).repeat(n)
         self.prev_potentials = self.potentials.clone()
         self.actions = torch.zeros(n, self.num_dof, device=dev)
+        self._forces = torch.zeros(n, self.num_dof, device=dev)
         self.seed = int(seed)
         self.reset_rand = None
         self._draws = 0
@@ -78,9 +79,12 @@ class HumanoidImitate(VecTask):
                     prev_potentials=self.prev_potentials, rew=self.rew_buf, reset=self.reset_buf,
                     progress=self.progress_buf, randomize=self.randomize_buf)
 
+    FUSED_ACTION_STAGE = True
+
     def pre_physics_step(self, actions):  # humanoid_imitate.py:627-632
-        self.actions = actions.to(self.device).clone()
-        self.sim.apply_dof_forces(self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale)
+        self._scale_actions(actions, self._forces, "force", gain=self.motor_efforts, power_scale=self.power_scale,
+                            keep=self.actions)
+        self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
         ops.humanoid_imitate_step(self._params(), self._buffers(), self.num_envs)

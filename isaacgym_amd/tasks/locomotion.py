@@ -72,6 +72,7 @@ class LocomotionTask(VecTask):
         self.potentials = torch.tensor([-1000.0 / self.dt], device=dev).repeat(n)
         self.prev_potentials = self.potentials.clone()
         self.actions = torch.zeros(n, self.num_dof, device=dev)
+        self._forces = torch.zeros(n, self.num_dof, device=dev)
         self.seed = int(seed)
         self.reset_rand = None  # optional [N, 2*num_dof] pre-drawn uniforms
         self._draws = 0
@@ -112,10 +113,12 @@ class LocomotionTask(VecTask):
             b["true_objective"] = self._true_objective
         return b
 
+    FUSED_ACTION_STAGE = True
+
     def pre_physics_step(self, actions):  # ant.py:368-374, humanoid.py:392-396
-        self.actions = actions.to(self.device).clone()
-        forces = self.actions * self.joint_gears.unsqueeze(0) * self.power_scale
-        self.sim.apply_dof_forces(forces)
+        self._scale_actions(actions, self._forces, "force", gain=self.joint_gears, power_scale=self.power_scale,
+                            keep=self.actions)
+        self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
         self._step_kernel(self._params(), self._buffers(), self.num_envs)

@@ -1169,6 +1169,195 @@ def gen_vectask(seed=21, N=301, T=3):
     print("vectask.npz", {k: (v.shape, v.dtype) for k, v in out.items() if hasattr(v, "shape")})
 
 
+def gen_prestep(seed=61, N=127, T=4):
+    """What surrounds the physics step on the action and observation side: the tasks'
+    pre_physics_step scaling (tasks/ant.py:368-374, tasks/humanoid.py:392-396,
+    tasks/amp/humanoid_amp_base.py:410-422 / :467-469, tasks/cartpole.py:164-168) and the
+    observation / action noise of the real VecTask.apply_randomizations + step
+    (tasks/base/vec_task.py:381-384, :407-412, :630-729)."""
+    import contextlib
+    import copy
+    import types
+    _install_gym_stubs()
+    sys.modules["isaacgym.gymtorch"].unwrap_tensor = lambda t: t
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+
+    class Gym:  # stands where the simulator stands; keeps what the task hands over
+        def __init__(self):
+            self.sent, self.frame = {}, 0
+
+        def get_frame_count(self, sim):
+            return self.frame
+
+        def set_dof_actuation_force_tensor(self, sim, t):
+            self.sent["force"] = t.clone()
+
+        def set_dof_position_target_tensor(self, sim, t):
+            self.sent["pd"] = t.clone()
+
+        def __getattr__(self, k):  # property getters / setters of the physical randomisation: unused
+            return _Any()
+
+    def fake(cls, **kw):
+        t = cls.__new__(cls)
+        t.device, t.gym, t.sim = "cpu", Gym(), None
+        for k, v in kw.items():
+            setattr(t, k, v)
+        return t
+
+    # ---- action scaling of the four task classes ----
+    ant = ref_shim.load("isaacgymenvs.tasks.ant").Ant
+    hum = ref_shim.load("isaacgymenvs.tasks.humanoid").Humanoid
+    amp = ref_shim.load("isaacgymenvs.tasks.amp.humanoid_amp_base").HumanoidAMPBase
+    cart = ref_shim.load("isaacgymenvs.tasks.cartpole").Cartpole
+    a8 = torch.randn(N, 8, generator=g) * 1.5
+    gears = torch.rand(8, generator=g) * 135.0 + 15.0
+    for tag, ps in (("ant", _cfg("Ant")["env"]["powerScale"]), ("ant_ps037", 0.37)):
+        t = fake(ant, joint_gears=gears, power_scale=ps)
+        t.pre_physics_step(a8)
+        out.update({tag + "_actions": a8.numpy().copy(), tag + "_gain": gears.numpy().copy(),
+                    tag + "_forces": t.gym.sent["force"].numpy().copy(), tag + "_self_actions": t.actions.numpy().copy()})
+        out[tag + "_power_scale"] = np.float64(ps)
+    a21 = torch.randn(N, 21, generator=g)
+    efforts = torch.rand(21, generator=g) * 180.0 + 20.0
+    t = fake(hum, motor_efforts=efforts, power_scale=_cfg("Humanoid")["env"]["powerScale"])
+    t.pre_physics_step(a21)
+    out.update(humanoid_actions=a21.numpy().copy(), humanoid_gain=efforts.numpy().copy(),
+               humanoid_forces=t.gym.sent["force"].numpy().copy(), humanoid_power_scale=np.float64(t.power_scale))
+    a28 = torch.randn(N, 28, generator=g)
+    off28, sc28 = torch.randn(28, generator=g) * 0.4, torch.rand(28, generator=g) * 2.0 + 0.3
+    eff28 = torch.rand(28, generator=g) * 180.0 + 20.0
+    for pd in (True, False):
+        t = fake(amp, _pd_control=pd, _pd_action_offset=off28, _pd_action_scale=sc28, motor_efforts=eff28,
+                 power_scale=_cfg("HumanoidAMP")["env"]["powerScale"])
+        t.pre_physics_step(a28)
+        out["amp_pd_targets" if pd else "amp_forces"] = t.gym.sent["pd" if pd else "force"].numpy().copy()
+    out.update(amp_actions=a28.numpy().copy(), amp_offset=off28.numpy().copy(), amp_scale=sc28.numpy().copy(),
+               amp_efforts=eff28.numpy().copy(), amp_power_scale=np.float64(t.power_scale))
+    a1 = torch.randn(N, 1, generator=g)
+    t = fake(cart, num_envs=N, num_dof=2, max_push_effort=_cfg("Cartpole")["env"]["maxEffort"])
+    t.pre_physics_step(a1)
+    out.update(cartpole_actions=a1.numpy().copy(), cartpole_forces=t.gym.sent["force"].numpy().copy(),
+               cartpole_max_push=np.float64(t.max_push_effort))
+
+    # ---- observation / action noise through the real VecTask ----
+    vt = ref_shim.load_real_vec_task()
+    variants = {
+        "v1": dict(frequency=3, frames=[25, 26, 27, 28], num_obs=13, clip_obs=5.0, clip_actions=1.0,
+                   observations=dict(range=[0.01, 0.3], range_correlated=[0.02, 0.1], operation="additive",
+                                     distribution="gaussian", schedule="linear", schedule_steps=40),
+                   actions=dict(range=[0.8, 1.2], range_correlated=[0.95, 1.05], operation="scaling",
+                                distribution="uniform", schedule="constant", schedule_steps=10)),
+        "v2": dict(frequency=2, frames=[3, 4, 5, 6], num_obs=60, clip_obs=float("inf"), clip_actions=0.9,
+                   observations=dict(range=[0.9, 1.1], range_correlated=[0.97, 1.02], operation="scaling",
+                                     distribution="uniform"),
+                   actions=dict(range=[0.0, 0.1], range_correlated=[0.01, 0.03], operation="additive",
+                                distribution="gaussian", schedule="linear", schedule_steps=8)),
+    }
+    draws = []
+    real_randn, real_rand = torch.randn_like, torch.rand_like
+
+    @contextlib.contextmanager
+    def record_draws():
+        def randn_like(t, *a, **k):
+            r = real_randn(t, *a, **k)
+            draws.append(("randn", r.numpy().copy()))
+            return r
+
+        def rand_like(t, *a, **k):
+            r = real_rand(t, *a, **k)
+            draws.append(("rand", r.numpy().copy()))
+            return r
+        torch.randn_like, torch.rand_like = randn_like, rand_like
+        try:
+            yield
+        finally:
+            torch.randn_like, torch.rand_like = real_randn, real_rand
+
+    for name, v in variants.items():
+        frames = []
+
+        class Task(vt.VecTask):
+            def __init__(self):
+                pass
+
+            def pre_physics_step(self, actions):
+                self.actions = actions.clone()
+
+            def post_physics_step(self):
+                f = frames[self.control_steps]
+                self.obs_buf[:] = f["obs"]
+                self.reset_buf[:] = f["reset"]
+                self.progress_buf[:] = f["progress"]
+
+        t = Task()
+        t.num_environments, t.num_observations, t.num_states, t.num_actions = N, v["num_obs"], 0, 5
+        t.device = t.rl_device = "cpu"
+        t.clip_obs, t.clip_actions = v["clip_obs"], v["clip_actions"]
+        t.dr_randomizations, t.control_freq_inv, t.force_render = {}, 1, False
+        t.gym, t.sim, t.control_steps, t.obs_dict = Gym(), None, 0, {}
+        t.max_episode_length = 50
+        t.first_randomization, t.last_rand_step, t.last_step = True, -1, -1
+        t.actor_params_generator, t.envs, t.original_props, t.sim_initialized = None, [], {}, True
+        t.allocate_buffers()
+        dr = dict(frequency=v["frequency"], observations=v["observations"], actions=v["actions"], actor_params={})
+        rec = {k: [] for k in ("in_actions", "in_obs", "in_reset", "in_progress", "self_actions", "obs_buf_after",
+                               "out_obs", "time_outs", "act_corr", "act_fresh", "obs_corr", "obs_fresh",
+                               "act_params", "obs_params", "randomize_before", "randomize_after", "did_randomize")}
+        torch.manual_seed(seed + len(name))
+        for step in range(T):
+            obs = torch.randn(N, v["num_obs"], generator=g) * 3.0
+            frames.append(dict(obs=obs, reset=(torch.rand(N, generator=g) < 0.4).long(),
+                               progress=torch.randint(0, 52, (N,), generator=g)))
+            # the tasks call apply_randomizations from reset_idx / pre_physics_step, i.e. before the step
+            t.gym.frame = v["frames"][step]
+            t.randomize_buf[:] = torch.randint(0, 5, (N,), generator=g)
+            rec["randomize_before"].append(t.randomize_buf.numpy().copy())
+            before = t.last_rand_step
+            t.apply_randomizations(copy.deepcopy(dr))
+            rec["did_randomize"].append(int(t.last_rand_step != before))
+            rec["randomize_after"].append(t.randomize_buf.numpy().copy())
+
+            def params(d):
+                keys = ("mu", "var", "mu_corr", "var_corr") if "mu" in d else ("lo", "hi", "lo_corr", "hi_corr")
+                return np.array([d[k] for k in keys], np.float64)
+            rec["act_params"].append(params(t.dr_randomizations["actions"]))
+            rec["obs_params"].append(params(t.dr_randomizations["observations"]))
+            a = torch.randn(N, 5, generator=g)
+            del draws[:]
+            with record_draws():
+                obs_dict, rew, reset, extras = t.step(a)
+            kinds = [k for k, _ in draws]
+            # per lambda: an optional new 'corr' draw (randn) followed by this call's draw
+            act_fresh_kind = "rand" if v["actions"]["distribution"] == "uniform" else "randn"
+            obs_fresh_kind = "rand" if v["observations"]["distribution"] == "uniform" else "randn"
+            i = 0
+            new_corr = len(draws) == 4
+            assert len(draws) in (2, 4), kinds
+            if new_corr:
+                act_corr = draws[i][1]; i += 1
+            act_fresh = draws[i][1]; assert draws[i][0] == act_fresh_kind; i += 1
+            if new_corr:
+                obs_corr = draws[i][1]; i += 1
+            obs_fresh = draws[i][1]; assert draws[i][0] == obs_fresh_kind
+            rec["act_corr"].append(act_corr); rec["act_fresh"].append(act_fresh)
+            rec["obs_corr"].append(obs_corr); rec["obs_fresh"].append(obs_fresh)
+            rec["in_actions"].append(a.numpy().copy()); rec["in_obs"].append(obs.numpy().copy())
+            rec["in_reset"].append(frames[-1]["reset"].numpy().copy())
+            rec["in_progress"].append(frames[-1]["progress"].numpy().copy())
+            rec["self_actions"].append(t.actions.numpy().copy())
+            rec["obs_buf_after"].append(t.obs_buf.numpy().copy())
+            rec["out_obs"].append(obs_dict["obs"].numpy().copy())
+            rec["time_outs"].append(extras["time_outs"].numpy().copy())
+        for k, lst in rec.items():
+            out["%s_%s" % (name, k)] = np.stack([np.asarray(x) for x in lst])
+    meta_variants = {k: dict(v, clip_obs=(None if math.isinf(v["clip_obs"]) else v["clip_obs"])) for k, v in variants.items()}
+    out["meta"] = _meta(task="prestep", seed=seed, N=N, T=T, variants=meta_variants, max_episode_length=50)
+    np.savez_compressed(os.path.join(OUT, "prestep.npz"), **out)
+    print("prestep.npz", {k: (v.shape, str(v.dtype)) for k, v in out.items() if hasattr(v, "shape")})
+
+
 def gen_episode_stats(seed=31, N=777, T=6):
     """The reward / length bookkeeping at learning/common_agent.py:284-296.  That module imports
     rl_games (absent), so the expressions of the call site are evaluated here with torch on
@@ -1209,7 +1398,7 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -205,6 +205,45 @@ def vec_task_tail(obs_buf, clip_obs, progress, reset, max_episode_length):
     return out, (progress >= max_episode_length - 1) & (reset != 0)
 
 
+# ---- noise lambdas and the action stage: numpy restatement (every numpy fp32 array
+# operation rounds once, as the ATen CPU kernels do) ----------------------------------
+def noise_apply(x, corr, fresh, corr_scale, corr_shift, scale, shift, operation):
+    """tasks/base/vec_task.py:693-701 (gaussian) and :720-727 (uniform): the Python floats
+    (var_corr, mu_corr, var, mu or the hi - lo differences, taken in double) enter the
+    fp32 tensor arithmetic rounded to fp32."""
+    f = np.float32
+    x, corr, fresh = (np.asarray(a, f) for a in (x, corr, fresh))
+    c = corr * f(corr_scale) + f(corr_shift)
+    noise = (c + fresh * f(scale)) + f(shift)
+    return (x * noise if operation == "scaling" else x + noise).astype(f)
+
+
+def clamp(x, lo, hi):
+    return np.minimum(np.maximum(np.asarray(x, np.float32), np.float32(lo)), np.float32(hi)).astype(np.float32)
+
+
+def action_stage(actions, mode, gain=None, offset=None, power_scale=1.0, clip_actions=np.inf, num_dof=0, noise=None):
+    """tasks/base/vec_task.py:381-384 then the task's pre_physics_step scaling
+    (tasks/ant.py:369-370, tasks/humanoid.py:393-394, tasks/amp/humanoid_amp_base.py:413-418,
+    :467-469, tasks/cartpole.py:164-166).  noise: dict of noise_apply's keyword arguments
+    (corr, fresh, ...) or None.  Returns (actions after noise and clamp, forces / targets)."""
+    f = np.float32
+    a = np.asarray(actions, f)
+    if noise is not None:
+        a = noise_apply(a, **noise)
+    a = clamp(a, -clip_actions, clip_actions)
+    if mode == "force":
+        t = (a * np.asarray(gain, f)) * f(power_scale)
+    elif mode == "pd_target":
+        t = np.asarray(offset, f) + np.asarray(gain, f) * a
+    elif mode == "first_dof":
+        t = np.zeros((a.size, num_dof), f)
+        t[:, 0] = a.reshape(-1) * f(power_scale)
+    else:
+        raise ValueError(mode)
+    return a, t.astype(f)
+
+
 def episode_stats_step(bufs, n):
     """In place on current_rewards / current_lengths; returns (n_done, sum_reward, sum_length)."""
     b = _abi.make_buffers(_abi.EpisodeBuffers, bufs, _np_ptr)

@@ -51,6 +51,10 @@ int main(void){
   printf("AmpParams %zu\n", sizeof(igx_amp_params));
   printf("AmpBuffers %zu\n", sizeof(igx_amp_buffers));
   printf("VecTaskTail %zu\n", sizeof(igx_vec_task_tail));
+  printf("Noise %zu\n", sizeof(igx_noise));
+  printf("ActionStage %zu\n", sizeof(igx_action_stage));
+  printf("off_noise %zu\n", offsetof(igx_vec_task_tail, obs_noise));
+  printf("off_mode %zu\n", offsetof(igx_action_stage, mode));
   printf("off_seed %zu\n", offsetof(igx_allegro_params, seed));
   printf("off_clip %zu\n", offsetof(igx_vec_task_tail, clip_obs));
   return 0; }
@@ -67,6 +71,10 @@ int main(void){
             assert _abi.AllegroParams.seed.offset == int(size)
         elif name == "off_clip":
             assert _abi.VecTaskTail.clip_obs.offset == int(size)
+        elif name == "off_noise":
+            assert _abi.VecTaskTail.obs_noise.offset == int(size)
+        elif name == "off_mode":
+            assert _abi.ActionStage.mode.offset == int(size)
         else:
             assert ctypes.sizeof(getattr(_abi, name)) == int(size), name
 
@@ -94,6 +102,12 @@ def test_every_entry_point_rejects_null_structs():
     assert lib.igx_motion_state(None, None, None, 4, None, None) == _abi.IGX_E_NULL
     assert lib.igx_vec_task_tail_step(None, 4, None) == _abi.IGX_E_NULL
     assert lib.igx_clamp(None, -1.0, 1.0, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_noise_apply(None, None, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_action_stage_step(None, 4, None) == _abi.IGX_E_NULL
+    stage = _abi.ActionStage(mode=7, num_actions=8, clip_actions=1.0)
+    assert lib.igx_action_stage_step(ctypes.byref(stage), 4, None) == _abi.IGX_E_PARAM
+    stage = _abi.ActionStage(mode=_abi.IGX_ACT_FIRST_DOF, num_actions=2, num_dof=2, clip_actions=1.0, actions=16, targets=16)
+    assert lib.igx_action_stage_step(ctypes.byref(stage), 4, None) == _abi.IGX_E_PARAM
     assert lib.igx_quat_mul(None, None, None, 4, None) == _abi.IGX_E_NULL
     # empty batches are valid no-ops even with NULL pointers
     assert lib.igx_clamp(None, -1.0, 1.0, None, 0, None) == 0
