@@ -211,19 +211,34 @@ struct AllegroWorkspace {
     unsigned long long num_resets;
     double finished;
 };
+// Workspace records: 0 = the reduced sums of the last call, 1.. = one record per tile.
+constexpr int WS_RESULT = 0, WS_TILES = 1;
 
-template <int OBS, bool REWARD>
+// :714-719 from the two global sums
+__device__ __forceinline__ void update_consecutive_successes(const igx_allegro_params &p, const igx_allegro_buffers &b,
+                                                             unsigned long long num_resets, double finished)
+{
+    const float fin = (float)finished;
+    if (num_resets > 0) {
+        const float cons = b.consecutive_successes[0];
+        b.consecutive_successes[0] = p.av_factor * fin / (float)(long long)num_resets + p.one_minus_av_factor * cons;
+    }
+}
+
+// T environments per tile (one wavefront each)
+template <int OBS, bool REWARD, int T>
 __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
                                                             float *__restrict__ obs_out, int64_t n)
 {
     using L = AllegroLayout<OBS>;
     constexpr int NOBS = L::NOBS;
-    __shared__ __align__(16) float s_tile[WAVE * NOBS];
+    static_assert(T == 32 || T == 64, "tile rows");
+    __shared__ __align__(16) float s_tile[T * NOBS];
     __shared__ __align__(16) float s_lim[2 * AD];
     const int lane = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * WAVE;
-    const int nvalid = (n - base >= WAVE) ? WAVE : (int)(n - base);
-    const bool full = nvalid == WAVE;
+    const int64_t base = (int64_t)blockIdx.x * T;
+    const int nvalid = (n - base >= T) ? T : (int)(n - base);
+    const bool full = nvalid == T;
     const bool live = lane < nvalid;
     const int64_t e = base + lane;
     if (lane < 2 * AD) s_lim[lane] = lane < AD ? p.dof_lower[lane] : p.dof_upper[lane - AD];
@@ -232,7 +247,8 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
     int64_t prog = 0, rst = 0, rg = 0, rnd = 0;
     float succ = 0.0f;
     float obj[13], goal[7];
-    v4f r_dof[AD * 2 / 4], r_force[AD / 4], r_act[AD / 4], r_goal[(WAVE * 13 / 4 + WAVE - 1) / WAVE];
+    v4f r_dof[T * AD * 2 / 4 / WAVE], r_force[T * AD / 4 / WAVE], r_act[T * AD / 4 / WAVE];
+    v4f r_goal[(T * 13 / 4 + WAVE - 1) / WAVE];
     if (live) {
         if (REWARD) {
             prog = ld_stream(b.progress + e);
@@ -241,8 +257,33 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
             succ = ld_stream(b.successes + e);
             if (b.randomize) rnd = ld_stream(b.randomize + e);
         }
-        // gathered actor row: three 16-byte loads at a 4-byte-aligned address and one scalar
-        const float *orow = b.root_state_tensor + b.object_indices[e] * 13;
+    }
+    // ---- object rows.  When the tile's actor indices are evenly spaced (index = first + s * lane,
+    // the layout every env-major simulator produces), the window of root-state rows they span is
+    // streamed as whole lines and the rows are picked out of LDS; any other index pattern is gathered
+    // row by row (three 16-byte loads at a 4-byte-aligned address and one scalar per lane).
+    constexpr int MAX_S = (T * NOBS / 13 - 1) / (T - 1) < 4 ? (T * NOBS / 13 - 1) / (T - 1) : 4;
+    constexpr int WIN_IT = (((MAX_S * (T - 1) + 1) * 13 + 3) / 4 + WAVE - 1) / WAVE;
+    const int64_t oidx = live ? b.object_indices[e] : 0;
+    const int64_t oidx0 = __shfl(oidx, 0);
+    const int64_t ostride = __shfl(oidx, 1) - oidx0;
+    const bool windowed = full && ostride >= 1 && ostride <= MAX_S &&
+                          __ballot(lane >= T || oidx == oidx0 + ostride * lane) == ~0ull;
+    const int win_floats = windowed ? ((int)ostride * (T - 1) + 1) * 13 : 0;
+    const float *win = b.root_state_tensor + oidx0 * 13;
+    v4f r_win[WIN_IT];
+    float r_win_tail = 0.0f;
+    if (windowed) {
+#pragma unroll
+        for (int it = 0; it < WIN_IT; ++it) {
+            const int k = lane + it * WAVE;
+            if (4 * k + 4 <= win_floats) r_win[it] = ld_stream_u(win + 4 * k);
+        }
+        // the last one to three floats of the window; reading a whole chunk there could leave the tensor
+        const int tail0 = win_floats & ~3;
+        if (tail0 + lane < win_floats) r_win_tail = __builtin_nontemporal_load(win + tail0 + lane);
+    } else if (live) {
+        const float *orow = b.root_state_tensor + oidx * 13;
         const v4f o0 = ld_stream_u(orow), o1 = ld_stream_u(orow + 4), o2 = ld_stream_u(orow + 8);
         obj[0] = o0.x; obj[1] = o0.y; obj[2] = o0.z; obj[3] = o0.w;
         obj[4] = o1.x; obj[5] = o1.y; obj[6] = o1.z; obj[7] = o1.w;
@@ -250,34 +291,52 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         obj[12] = __builtin_nontemporal_load(orow + 12);
     }
     if (full) {
-        load_chunks<WAVE * AD * 2 / 4>(b.dof_state + base * (2 * AD), r_dof, lane);
-        if (L::FORCE) load_chunks<WAVE * AD / 4>(b.dof_force + base * AD, r_force, lane);
-        load_chunks<WAVE * AD / 4>(b.actions + base * AD, r_act, lane);
-        load_chunks<WAVE * 13 / 4>(b.goal_states + base * 13, r_goal, lane);
+        load_chunks<T * AD * 2 / 4>(b.dof_state + base * (2 * AD), r_dof, lane);
+        if (L::FORCE) load_chunks<T * AD / 4>(b.dof_force + base * AD, r_force, lane);
+        load_chunks<T * AD / 4>(b.actions + base * AD, r_act, lane);
+        load_chunks<T * 13 / 4>(b.goal_states + base * 13, r_goal, lane);
     }
 
     // ---- goal rows: transpose through the (still empty) tile
-    park_rows<13>(r_goal, b.goal_states + base * 13, s_tile, nvalid, lane);
+    park_rows<13, T>(r_goal, b.goal_states + base * 13, s_tile, nvalid, lane);
     wave_sync();
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) goal[i] = s_tile[lane * 13 + i];
+        for (int i = 0; i < 7; ++i) goal[i] = s_tile[lane * 13 + i];
+    }
     wave_sync();
+    if (windowed) {  // uniform over the wave: the window goes through the tile the same way
+#pragma unroll
+        for (int it = 0; it < WIN_IT; ++it) {
+            const int k = lane + it * WAVE;
+            if (4 * k + 4 <= win_floats) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_win[it];
+        }
+        const int tail0 = win_floats & ~3;
+        if (tail0 + lane < win_floats) s_tile[tail0 + lane] = r_win_tail;
+        wave_sync();
+        if (live) {
+            const float *orow = s_tile + (int)ostride * lane * 13;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) obj[i] = orow[i];
+        }
+        wave_sync();
+    }
 
     // ---- stage pass-through columns
     if (full) {
         if constexpr (L::VEL) {
-            stage_dof_state<AD, NOBS, L::C_POS, L::C_VEL>(r_dof, s_tile, s_lim, p.vel_obs_scale, lane);
+            stage_dof_state<AD, NOBS, L::C_POS, L::C_VEL, T>(r_dof, s_tile, s_lim, p.vel_obs_scale, lane);
         } else {  // positions only
 #pragma unroll
-            for (int it = 0; it < AD * 2 / 4; ++it) {
+            for (int it = 0; it < T * AD * 2 / 4 / WAVE; ++it) {
                 const int pr = 2 * (lane + it * WAVE);
                 const int env = pr / AD, j = pr - env * AD;
                 s_tile[env * NOBS + L::C_POS + j] = unscale(r_dof[it].x, s_lim[j], s_lim[AD + j]);
                 s_tile[env * NOBS + L::C_POS + j + 1] = unscale(r_dof[it].z, s_lim[j + 1], s_lim[AD + j + 1]);
             }
         }
-        if constexpr (L::FORCE) stage_rows<AD, L::C_FORCE, NOBS, true>(r_force, s_tile, p.force_torque_obs_scale, lane);
-        stage_rows<AD, L::C_ACT, NOBS, false>(r_act, s_tile, 1.0f, lane);
+        if constexpr (L::FORCE) stage_rows<AD, L::C_FORCE, NOBS, true, T>(r_force, s_tile, p.force_torque_obs_scale, lane);
+        stage_rows<AD, L::C_ACT, NOBS, false, T>(r_act, s_tile, 1.0f, lane);
     } else {
         for (int i = lane; i < nvalid * AD; i += WAVE) {
             const int env = i / AD, j = i - env * AD;
@@ -350,7 +409,12 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
             fin = succ * (float)resets;
         }
     }
-    if (REWARD) {  // wave-level partial sums -> workspace
+    wave_sync();
+    drain_rows<NOBS, T>(obs_out + base * NOBS, s_tile, nvalid, lane);
+    if (REWARD && OBS == IGX_ALLEGRO_OBS_FULL_STATE && b.states)  // asymmetric observations: same 88 columns
+        drain_rows<NOBS, T>(b.states + base * NOBS, s_tile, nvalid, lane);
+
+    if (REWARD) {  // this tile's partial sums -> its record
         float f = fin;
         long long cnt = resets;
 #pragma unroll
@@ -358,31 +422,32 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
             f += __shfl_xor(f, off);
             cnt += __shfl_xor(cnt, off);
         }
-        if (lane == 0) {  // this tile's record; record 0 is reserved for the reduced sums
-            AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace) + 1 + blockIdx.x;
+        if (lane == 0) {
+            AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace) + WS_TILES + blockIdx.x;
             ws->num_resets = (unsigned long long)cnt;
             ws->finished = (double)f;
         }
     }
-    wave_sync();
-    drain_rows<NOBS>(obs_out + base * NOBS, s_tile, nvalid, lane);
-    if (REWARD && OBS == IGX_ALLEGRO_OBS_FULL_STATE && b.states)  // asymmetric observations: same 88 columns
-        drain_rows<NOBS>(b.states + base * NOBS, s_tile, nvalid, lane);
 }
 
 // The tiles' records are added in a fixed order (thread t takes records t, t + 1024, ...,
 // then a binary tree over the threads), so the sums do not depend on scheduling.
-// Result -> record 0 of the workspace.
-__global__ __launch_bounds__(1024) void allegro_reduce_kernel(AllegroWorkspace *ws, int64_t num_tiles)
+// Result -> record 0 of the workspace; FINALIZE applies it to consecutive_successes.
+// (A last-tile-reduces scheme inside the step kernel was measured: the device-scope
+// release it needs on every tile costs six times the whole step.)
+template <bool FINALIZE>
+__global__ __launch_bounds__(1024) void allegro_reduce_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
+                                                              int64_t num_tiles)
 {
     __shared__ unsigned long long s_cnt[1024];
     __shared__ double s_fin[1024];
+    AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
     const int t = threadIdx.x;
     unsigned long long cnt = 0;
     double fin = 0.0;
     for (int64_t i = t; i < num_tiles; i += 1024) {
-        cnt += ws[1 + i].num_resets;
-        fin += ws[1 + i].finished;
+        cnt += ws[WS_TILES + i].num_resets;
+        fin += ws[WS_TILES + i].finished;
     }
     s_cnt[t] = cnt;
     s_fin[t] = fin;
@@ -395,14 +460,14 @@ __global__ __launch_bounds__(1024) void allegro_reduce_kernel(AllegroWorkspace *
         __syncthreads();
     }
     if (t == 0) {
-        ws[0].num_resets = s_cnt[0];
-        ws[0].finished = s_fin[0];
+        ws[WS_RESULT].num_resets = s_cnt[0];
+        ws[WS_RESULT].finished = s_fin[0];
+        if (FINALIZE) update_consecutive_successes(p, b, s_cnt[0], s_fin[0]);
     }
 }
 
-// :714-719 consecutive_successes update from the two global sums: the records of
-// all shards (record 0 of this device's own workspace when there is one shard) are
-// added in index order, so every rank of a sharded run computes the same bits
+// consecutive_successes from the records of all shards, added in index order, so every
+// rank of a sharded run computes the same bits
 __global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
                                         const AllegroWorkspace *__restrict__ records, int num_records)
 {
@@ -412,11 +477,7 @@ __global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_al
         num_resets += records[i].num_resets;
         finished += records[i].finished;
     }
-    const float fin = (float)finished;
-    if (num_resets > 0) {
-        const float cons = b.consecutive_successes[0];
-        b.consecutive_successes[0] = p.av_factor * fin / (float)(long long)num_resets + p.one_minus_av_factor * cons;
-    }
+    update_consecutive_successes(p, b, num_resets, finished);
 }
 
 static int check_allegro(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, bool post,
@@ -474,39 +535,46 @@ extern "C" int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_al
     return launch_status("igx_allegro_pre_physics");
 }
 
-// observation / reward launches; leaves this shard's {num_resets, sum(successes * resets)}
-// record in b->workspace
-static int allegro_post_launch(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, igx_stream_t stream)
+template <int OBS, bool REWARD, int T>
+static void launch_post(const igx_allegro_params *p, const igx_allegro_buffers *b, float *obs_out, int64_t n, int reserve,
+                        hipStream_t s)
 {
-    int rc;
-    static const int reserve = tuning_int("IGX_ALLEGRO_LDS_RESERVE", 0);  // unused LDS: caps the waves per CU
-    const unsigned tiles = (unsigned)((n + WAVE - 1) / WAVE);
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned tiles = (unsigned)((n + T - 1) / T);
+    hipLaunchKernelGGL((allegro_post_kernel<OBS, REWARD, T>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b, obs_out, n);
+}
+
+template <int T>
+static int allegro_post_launch_t(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, int reserve,
+                                 bool finalize, hipStream_t s)
+{
     switch (p->obs_type) {
-    case IGX_ALLEGRO_OBS_FULL_NO_VEL:
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_NO_VEL, true>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b,
-                           b->obs, n);
-        break;
-    case IGX_ALLEGRO_OBS_FULL:
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL, true>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b,
-                           b->obs, n);
-        break;
-    default:
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, true>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p, *b,
-                           b->obs, n);
-        break;
+    case IGX_ALLEGRO_OBS_FULL_NO_VEL: launch_post<IGX_ALLEGRO_OBS_FULL_NO_VEL, true, T>(p, b, b->obs, n, reserve, s); break;
+    case IGX_ALLEGRO_OBS_FULL: launch_post<IGX_ALLEGRO_OBS_FULL, true, T>(p, b, b->obs, n, reserve, s); break;
+    default: launch_post<IGX_ALLEGRO_OBS_FULL_STATE, true, T>(p, b, b->obs, n, reserve, s); break;
     }
-    rc = launch_status("igx_allegro_post_physics");
+    int rc = launch_status("igx_allegro_post_physics");
     if (rc != IGX_OK) return rc;
     if (b->states && p->obs_type != IGX_ALLEGRO_OBS_FULL_STATE) {  // asymmetric critic state beside a smaller policy obs
-        hipLaunchKernelGGL((allegro_post_kernel<IGX_ALLEGRO_OBS_FULL_STATE, false>), dim3(tiles), dim3(WAVE), (size_t)reserve, s, *p,
-                           *b, b->states, n);
+        launch_post<IGX_ALLEGRO_OBS_FULL_STATE, false, T>(p, b, b->states, n, reserve, s);
         rc = launch_status("igx_allegro_post_physics(states)");
         if (rc != IGX_OK) return rc;
     }
-    hipLaunchKernelGGL(allegro_reduce_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<AllegroWorkspace *>(b->workspace),
-                       (int64_t)tiles);
+    const int64_t tiles = (n + T - 1) / T;
+    if (finalize) hipLaunchKernelGGL(allegro_reduce_kernel<true>, dim3(1), dim3(1024), 0, s, *p, *b, tiles);
+    else hipLaunchKernelGGL(allegro_reduce_kernel<false>, dim3(1), dim3(1024), 0, s, *p, *b, tiles);
     return launch_status("igx_allegro_post_physics(reduce)");
+}
+
+// observation / reward launch; leaves the {num_resets, sum(successes * resets)} sums of these
+// n environments in record 0 of b->workspace and, with `finalize`, applies them
+static int allegro_post_launch(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, bool finalize,
+                               igx_stream_t stream)
+{
+    static const int reserve = tuning_int("IGX_ALLEGRO_LDS_RESERVE", 6000);  // unused LDS: 5 waves per CU stream fastest
+    static const int tile = tuning_int("IGX_ALLEGRO_TILE", 64);           // environments per wavefront
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (tile == 32) return allegro_post_launch_t<32>(p, b, n, reserve, finalize, s);
+    return allegro_post_launch_t<64>(p, b, n, reserve, finalize, s);
 }
 
 extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
@@ -514,11 +582,7 @@ extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_a
 {
     int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics");
     if (rc != IGX_OK || n == 0) return rc;
-    rc = allegro_post_launch(p, b, n, stream);
-    if (rc != IGX_OK) return rc;
-    hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), *p, *b,
-                       reinterpret_cast<const AllegroWorkspace *>(b->workspace), 1);
-    return launch_status("igx_allegro_post_physics(finalize)");
+    return allegro_post_launch(p, b, n, true, stream);
 }
 
 extern "C" int igx_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
@@ -526,7 +590,7 @@ extern "C" int igx_allegro_post_physics_shard(const igx_allegro_params *p, const
 {
     int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics_shard");
     if (rc != IGX_OK || n == 0) return rc;
-    return allegro_post_launch(p, b, n, stream);
+    return allegro_post_launch(p, b, n, false, stream);
 }
 
 extern "C" int igx_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,

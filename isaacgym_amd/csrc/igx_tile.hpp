@@ -171,11 +171,11 @@ __device__ __forceinline__ void read_cols(const float *row, float (&out)[LEN])
 
 // Write the first COUNT floats of the LDS tile to global memory as whole
 // contiguous lines (full tile) or element by element (partial tile).
-template <int ROWW>
+template <int ROWW, int T = WAVE>
 __device__ __forceinline__ void drain_rows(float *__restrict__ g, const float *s_tile, int nvalid, int lane)
 {
-    if (nvalid == WAVE) {
-        constexpr int N4 = WAVE * ROWW / 4;
+    if (nvalid == T) {
+        constexpr int N4 = T * ROWW / 4;
         v4f *o4 = reinterpret_cast<v4f *>(g);
 #pragma unroll
         for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
@@ -189,12 +189,12 @@ __device__ __forceinline__ void drain_rows(float *__restrict__ g, const float *s
 
 // Park a tile's ROWW-float rows (chunks already in registers for a full tile,
 // or straight from global memory for a partial one) linearly at s.
-template <int ROWW, int ITERS>
+template <int ROWW, int T = WAVE, int ITERS = 1>
 __device__ __forceinline__ void park_rows(const v4f (&v)[ITERS], const float *__restrict__ g, float *s, int nvalid,
                                           int lane)
 {
-    if (nvalid == WAVE) {
-        constexpr int N4 = WAVE * ROWW / 4;
+    if (nvalid == T) {
+        constexpr int N4 = T * ROWW / 4;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int k = lane + it * WAVE;

@@ -14,7 +14,7 @@ kernel applies them.
 import numpy as np
 import torch
 
-from .. import _abi, distributed, ops
+from .. import _abi, distributed, ops, synthetic
 from .base.vec_task import VecTask
 
 
@@ -122,7 +122,7 @@ class AllegroHand(VecTask):
         self.seed = int(seed)
         self.reset_rand = None  # optional [N,45] pre-drawn uniforms
         self._draws = 0
-        self._workspace = torch.empty(4 * ((n + 63) // 64 + 1), device=dev)  # reduction scratch (16 B per tile + total)
+        self._workspace = torch.empty(synthetic.allegro_workspace_floats(n), device=dev)  # reduction scratch
         tol = self.success_tolerance * (2.0 if self.ignore_z else 1.0)
         self._success_c = success_threshold_c(tol)
         av32 = float(torch.tensor(self.av_factor, dtype=torch.float32))

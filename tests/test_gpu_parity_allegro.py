@@ -97,3 +97,38 @@ def test_allegro_two_shards_equal_one_on_device():
         H.assert_close(sh["consecutive_successes"].cpu().numpy(), full["consecutive_successes"].cpu().numpy(),
                        rtol=1e-6, what="consecutive_successes")
     assert torch.equal(shards[0][2]["consecutive_successes"], shards[1][2]["consecutive_successes"])
+
+
+@pytest.mark.parametrize("pattern", ["stride1", "stride2", "stride4", "stride5", "permuted", "mixed_tiles", "last_rows"])
+@pytest.mark.parametrize("obs_type", ["full_state", "full_no_vel"])
+def test_allegro_object_index_patterns(pattern, obs_type):
+    """Evenly spaced actor indices take the streamed-window path, anything else the row gather;
+    both must give the bits of the standard (3 * env + 1) layout.  'last_rows' puts the window
+    flush against the end of the tensor (no read may go past it: the allocation ends there)."""
+    n = 64 * 5 + 17
+    p = synthetic.allegro_params(obs_type, seed=5, rng_offset=1)
+    base = synthetic.allegro_state(n, 33, DEV, obs_type, False)
+    rows = base["root_state_tensor"][base["object_indices"]].clone()
+    env = torch.arange(n, device=DEV)
+    g = torch.Generator().manual_seed(7)
+    if pattern.startswith("stride"):
+        s = int(pattern[6:])
+        idx, total = s * env + (s - 1), s * n
+    elif pattern == "permuted":
+        idx, total = torch.randperm(3 * n, generator=g)[:n].to(DEV), 3 * n
+    elif pattern == "mixed_tiles":
+        idx = 3 * env + 1
+        tile = idx[64:128].clone()
+        idx[64:128] = tile[torch.randperm(64, generator=g).to(DEV)]
+        idx[200] += 1  # one irregular index inside an otherwise regular tile
+        total = 3 * n + 1
+    else:  # last_rows: stride 3 with the object row last in its env, tensor ends right after
+        idx, total = 3 * env + 2, 3 * n
+    root = torch.randn(total, 13, device=DEV)
+    root[idx] = rows
+    t = {k: (v.clone() if v is not None else None) for k, v in base.items()}
+    t["root_state_tensor"], t["object_indices"] = root.contiguous(), idx.contiguous()
+    ops.allegro_post_physics(p, base, n)
+    ops.allegro_post_physics(p, t, n)
+    for k in ("obs", "rew", "reset", "reset_goal", "progress", "successes", "consecutive_successes"):
+        assert torch.equal(base[k].view(torch.uint8), t[k].view(torch.uint8)), k
