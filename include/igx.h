@@ -178,22 +178,28 @@ typedef struct igx_imitate_args {
     int64_t n_total;            /* environments over all shards (== n_envs on one GPU) */
 } igx_imitate_args;
 
-#define IGX_QUANTILE_WORKSPACE_BYTES (64 + 2 * 2048 * 8)
+/* workspace: eight 64-byte states, then per pass two histograms of 2048 uint64 */
+#define IGX_QUANTILE_PASSES 6
+#define IGX_QUANTILE_HIST_OFFSET(pass) (512 + (pass) * (2 * 2048 * 8))
+#define IGX_QUANTILE_WORKSPACE_BYTES IGX_QUANTILE_HIST_OFFSET(IGX_QUANTILE_PASSES)
 
 /* everything in one call (one GPU) */
 int igx_ant_imitate_step(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
                          int64_t n_envs, igx_stream_t stream);
-/* the pieces, for environment-sharded runs: observe; then for pass = 0..5 { histogram;
- * all-reduce(sum) of the 2 x 2048 uint64 at workspace + 64 over the ranks; advance }; finish.
- * igx_quantile_begin zeroes the state and sets the two ranks from q and n_total. */
+/* the pieces, for environment-sharded runs: observe; igx_quantile_begin; then for pass = 0..5
+ * { igx_quantile_histogram; all-reduce(sum) over the ranks of the 2 x 2048 uint64 at workspace +
+ * IGX_QUANTILE_HIST_OFFSET(pass) }; igx_quantile_finish; igx_ant_imitate_finish.
+ * igx_quantile_begin zeroes the histograms and sets the two ranks from q and n_total; the
+ * histogram kernel of pass p first picks the bins of pass p - 1 from its (all-reduced) histogram;
+ * igx_quantile_finish picks the last digit and interpolates: the value goes to the workspace
+ * (where igx_ant_imitate_finish reads it) and to *out unless out is NULL. */
 int igx_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
                             int64_t n_envs, igx_stream_t stream);
 int igx_ant_imitate_finish(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
                            int64_t n_envs, igx_stream_t stream);
 int igx_quantile_begin(void *workspace, double q, int64_t n_total, igx_stream_t stream);
 int igx_quantile_histogram(const double *x, int64_t n, void *workspace, int32_t pass, igx_stream_t stream);
-int igx_quantile_advance(void *workspace, int32_t pass, igx_stream_t stream);
-#define IGX_QUANTILE_PASSES 6
+int igx_quantile_finish(void *workspace, double *out, igx_stream_t stream);
 /* torch.quantile(x, q) (linear interpolation) of n doubles -> *out (device); x must hold no NaN */
 int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream);
 

@@ -189,8 +189,14 @@ class ImitateArgs(_Struct):
                 ("quantile", C.c_double), ("distance_floor", C.c_double), ("death_cost", C.c_double), ("n_total", i64)]
 
 
-IGX_QUANTILE_WORKSPACE_BYTES = 64 + 2 * 2048 * 8
 IGX_QUANTILE_PASSES = 6
+
+
+def IGX_QUANTILE_HIST_OFFSET(p):
+    return 512 + p * (2 * 2048 * 8)
+
+
+IGX_QUANTILE_WORKSPACE_BYTES = IGX_QUANTILE_HIST_OFFSET(IGX_QUANTILE_PASSES)
 
 
 class EpisodeBuffers(_Struct):

@@ -1,11 +1,13 @@
 // Exact quantile of n doubles on the device (torch.quantile, 'linear' interpolation):
 // radix select of the two neighbouring order statistics, most significant digit
-// first, 6 passes over the data (9 + 5 x 11 bits).  Per pass: every workgroup
-// builds LDS histograms of the digit among the elements that match the prefix
-// found so far, flushes the non-empty bins with atomics (integer adds: the result
-// does not depend on their order), and a one-block kernel picks the bin that
-// holds each rank.  For environment-sharded runs the caller all-reduces the
-// histograms between the two kernels, which makes every rank pick the same bins.
+// first, 6 passes over the data (9 + 5 x 11 bits).  Per pass one kernel: every
+// workgroup first derives the prefix found so far from the previous pass's complete
+// histogram (all workgroups redundantly - 2048 bins, cheaper than a launch of its own),
+// builds LDS histograms of this pass's digit among the elements that match the prefix,
+// and flushes the non-empty bins with atomics (integer adds: the result does not depend
+// on their order).  Each pass has its own histogram, zeroed at the start, so an
+// environment-sharded run only has to all-reduce histogram `pass` between kernels
+// `pass` and `pass + 1`, which makes every rank pick the same bins.
 //
 // Reference: torch.quantile as called at IsaacGymEnvs/isaacgymenvs/tasks/ant_imitate.py:529
 // (sort, ranks = q * (n - 1), lerp between floor and ceil ranks).
@@ -16,8 +18,9 @@
 namespace igx {
 
 constexpr int QBINS = 2048;
+constexpr int QPASSES = IGX_QUANTILE_PASSES;
 
-struct QuantileState {  // 64 bytes, followed by hist[2][QBINS]
+struct QuantileState {  // 64 bytes; states[p] = after p digits; states[0].result also receives the final value
     unsigned long long prefix[2];
     unsigned long long rank[2];
     double weight;   // fractional part of q * (n - 1)
@@ -26,10 +29,17 @@ struct QuantileState {  // 64 bytes, followed by hist[2][QBINS]
     unsigned long long pad;
 };
 static_assert(sizeof(QuantileState) == 64, "state header");
-static_assert(IGX_QUANTILE_WORKSPACE_BYTES == 64 + 2 * QBINS * 8, "workspace size is part of the ABI");
+static_assert(IGX_QUANTILE_HIST_OFFSET(0) == 8 * sizeof(QuantileState), "room for the states of all passes");
+static_assert(IGX_QUANTILE_HIST_OFFSET(1) - IGX_QUANTILE_HIST_OFFSET(0) == 2 * QBINS * 8, "two histograms per pass");
+static_assert(IGX_QUANTILE_WORKSPACE_BYTES == IGX_QUANTILE_HIST_OFFSET(QPASSES), "workspace size is part of the ABI");
 
 __host__ __device__ inline int digit_bits(int pass) { return pass == 0 ? 9 : 11; }
 __host__ __device__ inline int digit_shift(int pass) { return pass == 0 ? 55 : 55 - 11 * pass; }
+
+__device__ __forceinline__ unsigned long long *hist_of(QuantileState *states, int pass)
+{
+    return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(states) + IGX_QUANTILE_HIST_OFFSET(pass));
+}
 
 // order-preserving map of a double's bits to an unsigned integer
 __device__ __forceinline__ unsigned long long key_of(double x)
@@ -43,30 +53,94 @@ __device__ __forceinline__ double value_of(unsigned long long k)
     return __longlong_as_double((long long)u);
 }
 
-__global__ void quantile_begin_kernel(QuantileState *st, unsigned long long *hist, double q, unsigned long long n_total)
+__global__ __launch_bounds__(256) void quantile_begin_kernel(QuantileState *states, double q, unsigned long long n_total)
 {
-    for (int i = threadIdx.x; i < 2 * QBINS; i += blockDim.x) hist[i] = 0;
-    if (threadIdx.x == 0) {
+    unsigned long long *hist = hist_of(states, 0);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < QPASSES * 2 * QBINS; i += gridDim.x * 256) hist[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double ranks = q * (double)(n_total - 1);
         const long long below = (long long)ranks;  // toType(kLong): truncation
         const long long above = (long long)ceil(ranks);
-        st->prefix[0] = st->prefix[1] = 0;
-        st->rank[0] = (unsigned long long)below;
-        st->rank[1] = (unsigned long long)above;
-        st->weight = ranks - (double)below;
-        st->result = 0.0;
-        st->n_total = n_total;
+        QuantileState st;
+        st.prefix[0] = st.prefix[1] = 0;
+        st.rank[0] = (unsigned long long)below;
+        st.rank[1] = (unsigned long long)above;
+        st.weight = ranks - (double)below;
+        st.result = 0.0;
+        st.n_total = n_total;
+        st.pad = 0;
+        states[0] = st;
     }
 }
 
-__global__ __launch_bounds__(256) void quantile_hist_kernel(const double *__restrict__ x, int64_t n, const QuantileState *st,
-                                                            unsigned long long *hist, int pass)
+// exclusive prefix sum over the 256 threads of the block
+__device__ __forceinline__ unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long *s_wave)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int i = 0; i < w; ++i) base += s_wave[i];
+    __syncthreads();
+    return base + inc - v;
+}
+
+// *out (LDS) = `in` advanced by digit `pass`, whose complete histogram is `hist`: the bin that
+// holds each rank.  Called by all 256 threads of a block; ends with a barrier.
+__device__ __forceinline__ void advance_state(const QuantileState *in, const unsigned long long *hist, int pass,
+                                              QuantileState *out, unsigned long long *s_wave)
+{
+    if (threadIdx.x == 0) *out = *in;
+    __syncthreads();
+    const int bits = digit_bits(pass), nb = 1 << bits;
+    const bool same = in->prefix[0] == in->prefix[1];
+    for (int r = 0; r < 2; ++r) {
+        const unsigned long long *h = hist + ((r == 1 && !same) ? QBINS : 0);
+        // 256 threads x 8 consecutive bins
+        unsigned long long loc[8], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bin = threadIdx.x * 8 + i;
+            loc[i] = bin < nb ? h[bin] : 0;
+            tot += loc[i];
+        }
+        unsigned long long run = block_exclusive_scan(tot, s_wave);
+        const unsigned long long rank = in->rank[r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (rank >= run && rank < run + loc[i]) {  // exactly one (thread, i) satisfies this
+                out->prefix[r] = (in->prefix[r] << bits) | (unsigned long long)(threadIdx.x * 8 + i);
+                out->rank[r] = rank - run;
+            }
+            run += loc[i];
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void quantile_hist_kernel(const double *__restrict__ x, int64_t n, QuantileState *states,
+                                                            int pass)
 {
     __shared__ unsigned s_hist[2][QBINS];
+    __shared__ unsigned long long s_wave[4];
+    __shared__ QuantileState s_st;
     for (int i = threadIdx.x; i < 2 * QBINS; i += 256) (&s_hist[0][0])[i] = 0;
-    __syncthreads();
+    if (pass == 0) {
+        if (threadIdx.x == 0) s_st = states[0];
+        __syncthreads();
+    } else {
+        advance_state(&states[pass - 1], hist_of(states, pass - 1), pass - 1, &s_st, s_wave);
+        if (blockIdx.x == 0 && threadIdx.x == 0) states[pass] = s_st;
+    }
+    unsigned long long *hist = hist_of(states, pass);
     const int shift = digit_shift(pass), bits = digit_bits(pass);
-    const unsigned long long p0 = st->prefix[0], p1 = st->prefix[1];
+    const unsigned long long p0 = s_st.prefix[0], p1 = s_st.prefix[1];
     const bool same = p0 == p1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const unsigned long long k = key_of(ld_stream(x + i));
@@ -82,53 +156,22 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const double *__rest
     }
 }
 
-// one block: the bin that holds each rank; histograms re-zeroed for the next pass
-__global__ __launch_bounds__(256) void quantile_advance_kernel(QuantileState *st, unsigned long long *hist, int pass)
+// one block: the last digit, then torch's lerp between the two order statistics
+__global__ __launch_bounds__(256) void quantile_finish_kernel(QuantileState *states, double *out)
 {
-    __shared__ unsigned long long s_sum[256];
-    const int bits = digit_bits(pass), nb = 1 << bits;
-    const bool same = st->prefix[0] == st->prefix[1];
-    for (int r = 0; r < 2; ++r) {
-        const unsigned long long *h = hist + ((r == 1 && !same) ? QBINS : 0);
-        // 256 threads x 8 consecutive bins
-        unsigned long long loc[8], tot = 0;
-        for (int i = 0; i < 8; ++i) {
-            const int bin = threadIdx.x * 8 + i;
-            loc[i] = bin < nb ? h[bin] : 0;
-            tot += loc[i];
-        }
-        s_sum[threadIdx.x] = tot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long run = 0;
-            for (int t = 0; t < 256; ++t) {
-                const unsigned long long v = s_sum[t];
-                s_sum[t] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        const unsigned long long rank = st->rank[r];
-        unsigned long long run = s_sum[threadIdx.x];
-        __syncthreads();
-        for (int i = 0; i < 8; ++i) {
-            if (rank >= run && rank < run + loc[i]) {  // exactly one (thread, i) satisfies this
-                st->prefix[r] = (st->prefix[r] << bits) | (unsigned long long)(threadIdx.x * 8 + i);
-                st->rank[r] = rank - run;
-            }
-            run += loc[i];
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 2 * QBINS; i += 256) hist[i] = 0;
-    if (pass == IGX_QUANTILE_PASSES - 1 && threadIdx.x == 0) {
-        const double a = value_of(st->prefix[0]), b = value_of(st->prefix[1]), w = st->weight;
+    __shared__ unsigned long long s_wave[4];
+    __shared__ QuantileState s_st;
+    advance_state(&states[QPASSES - 1], hist_of(states, QPASSES - 1), QPASSES - 1, &s_st, s_wave);
+    if (threadIdx.x == 0) {
+        const double a = value_of(s_st.prefix[0]), b = value_of(s_st.prefix[1]), w = s_st.weight;
         const double diff = b - a;  // at::native::lerp
-        st->result = (fabs(w) < 0.5) ? a + w * diff : b - diff * (1.0 - w);
+        const double r = (fabs(w) < 0.5) ? a + w * diff : b - diff * (1.0 - w);
+        s_st.result = r;
+        states[QPASSES] = s_st;
+        states[0].result = r;
+        if (out) *out = r;
     }
 }
-
-__global__ void quantile_result_kernel(const QuantileState *st, double *out) { *out = st->result; }
 
 static int check_ws(void *ws, const char *who)
 {
@@ -147,9 +190,8 @@ extern "C" int igx_quantile_begin(void *workspace, double q, int64_t n_total, ig
     if (rc != IGX_OK) return rc;
     if (!(q >= 0.0 && q <= 1.0)) return fail(IGX_E_PARAM, "igx_quantile_begin: q must lie in [0, 1]");
     if (n_total <= 0) return fail(IGX_E_SIZE, "igx_quantile_begin: n_total must be positive");
-    QuantileState *st = static_cast<QuantileState *>(workspace);
-    hipLaunchKernelGGL(quantile_begin_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), st,
-                       reinterpret_cast<unsigned long long *>(st + 1), q, (unsigned long long)n_total);
+    hipLaunchKernelGGL(quantile_begin_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<QuantileState *>(workspace), q, (unsigned long long)n_total);
     return launch_status("igx_quantile_begin");
 }
 
@@ -159,37 +201,30 @@ extern "C" int igx_quantile_histogram(const double *x, int64_t n, void *workspac
     if (rc != IGX_OK) return rc;
     if (pass < 0 || pass >= IGX_QUANTILE_PASSES) return fail(IGX_E_PARAM, "igx_quantile_histogram: pass %d", pass);
     if (n < 0) return fail(IGX_E_SIZE, "igx_quantile_histogram: negative n");
-    if (n == 0) return IGX_OK;  // an empty shard contributes nothing
-    if (!x) return fail(IGX_E_NULL, "igx_quantile_histogram: x is NULL");
-    QuantileState *st = static_cast<QuantileState *>(workspace);
+    if (n > 0 && !x) return fail(IGX_E_NULL, "igx_quantile_histogram: x is NULL");
+    // an empty shard contributes nothing but still advances its copy of the state
     int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 2048) blocks = 2048;
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
     hipLaunchKernelGGL(quantile_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n,
-                       st, reinterpret_cast<unsigned long long *>(st + 1), (int)pass);
+                       static_cast<QuantileState *>(workspace), (int)pass);
     return launch_status("igx_quantile_histogram");
 }
 
-extern "C" int igx_quantile_advance(void *workspace, int32_t pass, igx_stream_t stream)
+extern "C" int igx_quantile_finish(void *workspace, double *out, igx_stream_t stream)
 {
-    int rc = check_ws(workspace, "igx_quantile_advance");
+    int rc = check_ws(workspace, "igx_quantile_finish");
     if (rc != IGX_OK) return rc;
-    if (pass < 0 || pass >= IGX_QUANTILE_PASSES) return fail(IGX_E_PARAM, "igx_quantile_advance: pass %d", pass);
-    QuantileState *st = static_cast<QuantileState *>(workspace);
-    hipLaunchKernelGGL(quantile_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), st,
-                       reinterpret_cast<unsigned long long *>(st + 1), (int)pass);
-    return launch_status("igx_quantile_advance");
+    hipLaunchKernelGGL(quantile_finish_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<QuantileState *>(workspace), out);
+    return launch_status("igx_quantile_finish");
 }
 
 extern "C" int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream)
 {
     if (!out) return fail(IGX_E_NULL, "igx_quantile_f64: out is NULL");
     int rc = igx_quantile_begin(workspace, q, n, stream);
-    for (int pass = 0; rc == IGX_OK && pass < IGX_QUANTILE_PASSES; ++pass) {
+    for (int pass = 0; rc == IGX_OK && pass < IGX_QUANTILE_PASSES; ++pass)
         rc = igx_quantile_histogram(x, n, workspace, pass, stream);
-        if (rc == IGX_OK) rc = igx_quantile_advance(workspace, pass, stream);
-    }
     if (rc != IGX_OK) return rc;
-    hipLaunchKernelGGL(quantile_result_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const QuantileState *>(workspace), out);
-    return launch_status("igx_quantile_f64");
+    return igx_quantile_finish(workspace, out, stream);
 }

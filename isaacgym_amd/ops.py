@@ -311,12 +311,13 @@ def quantile_sharded(x, q, n_total, workspace, all_reduce):
     dev = workspace.device
     L = _lib.lib()
     ws = _lib.tensor_ptr(workspace)
-    hist = workspace.view(torch.int64)[8:8 + 2 * 2048]
+    words = workspace.view(torch.int64)
     with torch.cuda.device(dev):
         st = _lib.current_stream(dev)
         _lib.check(L.igx_quantile_begin(ws, C.c_double(q), C.c_int64(n_total), st))
         for p in range(_abi.IGX_QUANTILE_PASSES):
             _lib.check(L.igx_quantile_histogram(_lib.tensor_ptr(x, torch.float64), C.c_int64(x.numel()), ws, C.c_int32(p), st))
-            all_reduce(hist)
-            _lib.check(L.igx_quantile_advance(ws, C.c_int32(p), st))
+            off = _abi.IGX_QUANTILE_HIST_OFFSET(p) // 8
+            all_reduce(words[off:off + 2 * 2048])
+        _lib.check(L.igx_quantile_finish(ws, None, st))
     return workspace.view(torch.float64)[5].clone()

@@ -47,10 +47,12 @@ def test_quantile_sharded_equals_whole():
     for p in range(_abi.IGX_QUANTILE_PASSES):
         for ws, sh in zip(wss, shards):
             _lib.check(lib.igx_quantile_histogram(_lib.tensor_ptr(sh), C.c_int64(sh.numel()), _lib.tensor_ptr(ws), C.c_int32(p), st))
-        total = sum(ws[8:8 + 4096] for ws in wss)
+        off = _abi.IGX_QUANTILE_HIST_OFFSET(p) // 8
+        total = sum(ws[off:off + 4096] for ws in wss)
         for ws in wss:
-            ws[8:8 + 4096] = total
-            _lib.check(lib.igx_quantile_advance(_lib.tensor_ptr(ws), C.c_int32(p), st))
+            ws[off:off + 4096] = total
+    for ws in wss:
+        _lib.check(lib.igx_quantile_finish(_lib.tensor_ptr(ws), None, st))
     want = float(torch.quantile(x.cpu(), 0.99))
     for ws in wss:
         assert float(ws.view(torch.float64)[5]) == want
