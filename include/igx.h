@@ -342,6 +342,85 @@ int igx_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_b
                                 int32_t num_shards, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * ShadowHand in-hand reorientation (tasks/shadow_hand.py): the same task family as
+ * AllegroHand - compute_hand_reward :747-800 is the same function - with a 24-joint hand
+ * of which 20 joints are actuated (actuated_dof_indices), five fingertip bodies read out
+ * of rigid_body_states (fingertip_handles), fingertip force-torque sensors, and four
+ * observation layouts.
+ *  igx_shadow_pre_physics  = pre_physics_step :670-698 with reset_target_pose :586-602,
+ *      reset_idx :604-668 and randomize_rotation(_pen) :803-813 (forceScale 0: no random forces);
+ *  igx_shadow_post_physics = post_physics_step :710-715 with compute_observations :437-471,
+ *      compute_fingertip_observations :473-496, compute_full_observations :498-526,
+ *      compute_full_state :528-584 and compute_hand_reward.
+ * The workspace, the shard record and the finalize step are AllegroHand's.
+ * ---------------------------------------------------------------------- */
+#define IGX_SHADOW_DOF 24
+#define IGX_SHADOW_ACTIONS 20
+#define IGX_SHADOW_FINGERTIPS 5
+#define IGX_SHADOW_OBS_OPENAI 0      /* 42 columns  (:481-485) */
+#define IGX_SHADOW_OBS_FULL_NO_VEL 1 /* 77 columns  (:500-510) */
+#define IGX_SHADOW_OBS_FULL 2        /* 157 columns (:512-526) */
+#define IGX_SHADOW_OBS_FULL_STATE 3  /* 211 columns (:558-584), also the asymmetric states_buf */
+#define IGX_SHADOW_RAND_PER_ENV 61   /* 4 goal-only draws, 53 env-reset draws, 4 goal draws inside the env reset */
+
+typedef struct igx_shadow_params {
+    int32_t obs_type;                  /* IGX_SHADOW_OBS_* */
+    int32_t max_consecutive_successes;
+    int32_t ignore_z_rot;              /* object_type == "pen" */
+    int32_t use_relative_control;
+    float dist_reward_scale, rot_reward_scale, rot_eps, action_penalty_scale;
+    float success_tolerance;           /* already doubled for the pen */
+    float success_threshold_c;         /* as in igx_allegro_params */
+    float reach_goal_bonus, fall_dist, fall_penalty;
+    float max_episode_length_m1;
+    float av_factor, one_minus_av_factor;
+    float vel_obs_scale;               /* 0.2 */
+    float force_torque_obs_scale;      /* 10.0 */
+    float reset_position_noise, reset_dof_pos_noise, reset_dof_vel_noise;
+    float act_moving_average, one_minus_act_moving_average;
+    float dof_speed_scale_dt;
+    float goal_displacement[3];
+    int32_t num_bodies;                /* rigid bodies per environment (rows of rigid_body_states per env) */
+    float dof_lower[IGX_SHADOW_DOF], dof_upper[IGX_SHADOW_DOF];
+    int32_t actuated_dof_indices[IGX_SHADOW_ACTIONS]; /* strictly increasing, in [0, 24) */
+    int32_t fingertip_handles[IGX_SHADOW_FINGERTIPS]; /* body indices in [0, num_bodies) */
+    int32_t reserved;
+    uint64_t seed, rng_offset;
+} igx_shadow_params;
+
+typedef struct igx_shadow_buffers {
+    float *dof_state;                 /* [N,24,2] */
+    const float *dof_force;           /* [N,24]; full_state / asymmetric */
+    const float *vec_sensor_tensor;   /* [N,30]; full_state / asymmetric */
+    const float *rigid_body_states;   /* [N,num_bodies,13] */
+    float *root_state_tensor;         /* [3N,13] */
+    const int64_t *object_indices;    /* [N] */
+    const int64_t *goal_object_indices; /* [N] */
+    float *goal_states;               /* [N,13] */
+    const float *goal_init_state;     /* [N,13] */
+    const float *object_init_state;   /* [N,13] */
+    const float *actions;             /* [N,20] */
+    float *prev_targets, *cur_targets; /* [N,24] */
+    const float *rand;                /* [N,61] uniforms in [0,1); NULL = Philox */
+    float *obs;                       /* [N,42|77|157|211] out */
+    float *states;                    /* [N,211] out, asymmetric observations; may be NULL */
+    float *rew;                       /* [N] out */
+    int64_t *reset, *reset_goal, *progress; /* [N] in/out */
+    int64_t *randomize;               /* [N] += 1 in post; may be NULL */
+    float *successes;                 /* [N] in/out */
+    float *consecutive_successes;     /* [1] in/out */
+    void *workspace;                  /* IGX_ALLEGRO_WORKSPACE_BYTES(n_envs), 16-byte aligned, any contents */
+} igx_shadow_buffers;
+
+int igx_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n_envs, igx_stream_t stream);
+int igx_shadow_post_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n_envs, igx_stream_t stream);
+/* environment-sharded form, as igx_allegro_post_physics_shard / igx_allegro_finalize_shards */
+int igx_shadow_post_physics_shard(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n_envs,
+                                  igx_stream_t stream);
+int igx_shadow_finalize_shards(const igx_shadow_params *p, const igx_shadow_buffers *b, const void *records,
+                               int32_t num_shards, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * HumanoidAMP and the AMP motion library.  The character is the reference's
  * 15-body / 28-dof AMP humanoid: DOF_BODY_IDS, DOF_OFFSETS and the four key
  * bodies are fixed as in tasks/amp/humanoid_amp_base.py:43-49.

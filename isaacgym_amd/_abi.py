@@ -110,6 +110,40 @@ class AllegroBuffers(_Struct):
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
                 ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr)]
 
+IGX_SHADOW_DOF, IGX_SHADOW_ACTIONS, IGX_SHADOW_FINGERTIPS, IGX_SHADOW_RAND_PER_ENV = 24, 20, 5, 61
+IGX_SHADOW_OBS = {"openai": 0, "full_no_vel": 1, "full": 2, "full_state": 3}
+IGX_SHADOW_NUM_OBS = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}
+
+
+class ShadowParams(_Struct):
+    _fields_ = [("obs_type", i32), ("max_consecutive_successes", i32), ("ignore_z_rot", i32),
+                ("use_relative_control", i32),
+                ("dist_reward_scale", f32), ("rot_reward_scale", f32), ("rot_eps", f32),
+                ("action_penalty_scale", f32),
+                ("success_tolerance", f32), ("success_threshold_c", f32),
+                ("reach_goal_bonus", f32), ("fall_dist", f32), ("fall_penalty", f32),
+                ("max_episode_length_m1", f32),
+                ("av_factor", f32), ("one_minus_av_factor", f32),
+                ("vel_obs_scale", f32), ("force_torque_obs_scale", f32),
+                ("reset_position_noise", f32), ("reset_dof_pos_noise", f32), ("reset_dof_vel_noise", f32),
+                ("act_moving_average", f32), ("one_minus_act_moving_average", f32),
+                ("dof_speed_scale_dt", f32),
+                ("goal_displacement", f32 * 3), ("num_bodies", i32),
+                ("dof_lower", f32 * IGX_SHADOW_DOF), ("dof_upper", f32 * IGX_SHADOW_DOF),
+                ("actuated_dof_indices", i32 * IGX_SHADOW_ACTIONS), ("fingertip_handles", i32 * IGX_SHADOW_FINGERTIPS),
+                ("reserved", i32), ("seed", u64), ("rng_offset", u64)]
+
+
+class ShadowBuffers(_Struct):
+    _fields_ = [("dof_state", ptr), ("dof_force", ptr), ("vec_sensor_tensor", ptr), ("rigid_body_states", ptr),
+                ("root_state_tensor", ptr), ("object_indices", ptr), ("goal_object_indices", ptr),
+                ("goal_states", ptr), ("goal_init_state", ptr), ("object_init_state", ptr),
+                ("actions", ptr), ("prev_targets", ptr), ("cur_targets", ptr), ("rand", ptr),
+                ("obs", ptr), ("states", ptr), ("rew", ptr),
+                ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
+                ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr)]
+
+
 IGX_AMP_NUM_BODIES = 15
 IGX_AMP_NUM_DOF = 28
 IGX_AMP_NUM_KEY_BODIES = 4

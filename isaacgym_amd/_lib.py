@@ -32,6 +32,10 @@ SYMBOLS = {
     "igx_allegro_post_physics": _STEP_SIG,
     "igx_allegro_post_physics_shard": _STEP_SIG,
     "igx_allegro_finalize_shards": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "igx_shadow_pre_physics": _STEP_SIG,
+    "igx_shadow_post_physics": _STEP_SIG,
+    "igx_shadow_post_physics_shard": _STEP_SIG,
+    "igx_shadow_finalize_shards": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
 }
 SYMBOLS["igx_vec_task_tail_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_clamp"] = (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_int64, _P])

@@ -2,17 +2,15 @@
 // the action -> joint-target path) and post_physics_step (observations,
 // compute_hand_reward, cross-environment consecutive_successes update).
 //
-// Both kernels give a wavefront a tile of 64 consecutive environments.
+// Both kernels give a wavefront a tile of consecutive environments.
 // post: the tile's dof_state / dof_force / actions slices stream in with
 //   16-byte non-temporal loads and land in their final columns of the LDS image
-//   of the observation rows; lane i gathers its object's root row (indexed by
+//   of the observation rows; lane i takes its object's root row (addressed by
 //   object_indices) and its goal pose, writes the 24 (18) pose columns, and
 //   evaluates the reward from its own row; rows leave as whole lines.  The two
-//   global sums of compute_hand_reward are reduced per wave, added to a 16-byte
-//   workspace with one integer and one double atomic per wave (exact for the
-//   integer-valued success counts, hence order independent), and folded into
-//   consecutive_successes by a one-thread kernel that also re-zeroes the
-//   workspace.
+//   global sums of compute_hand_reward are reduced per wave into a record per
+//   tile and added in a fixed order by a one-block kernel, which also folds them
+//   into consecutive_successes.
 // pre: flagged environments are re-initialised one at a time by the whole wave
 //   (lane j = joint j), then the action path runs over the tile's [64,16]
 //   slab of targets with coalesced 16-byte accesses.
@@ -21,12 +19,12 @@
 // :722-732 (pre) and :627-632, :406-504, :663-719 (post).
 #include "igx_device.hpp"
 #include "igx_host.hpp"
+#include "igx_hand.hpp"
 #include "igx_tile.hpp"
 
 namespace igx {
 
 constexpr int AD = IGX_ALLEGRO_DOF;
-constexpr float PI_F = 3.14159274f;  // float32(np.pi)
 
 template <int OBS>
 struct AllegroLayout {
@@ -56,40 +54,6 @@ __device__ __forceinline__ float allegro_draw(const igx_allegro_params &p, const
         u = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
     }
     return 2.0f * u + (-1.0f);
-}
-
-// :722-725 randomize_rotation
-__device__ __forceinline__ f4 randomize_rotation(float r0, float r1)
-{
-    return quat_mul(quat_from_angle_axis(r0 * PI_F, f3{1.0f, 0.0f, 0.0f}),
-                    quat_from_angle_axis(r1 * PI_F, f3{0.0f, 1.0f, 0.0f}));
-}
-
-// :728-732 randomize_rotation_pen (max_angle 0.3)
-__device__ __forceinline__ f4 randomize_rotation_pen(float r0)
-{
-    return quat_mul(quat_from_angle_axis(1.57079637f + r0 * 0.3f, f3{1.0f, 0.0f, 0.0f}),
-                    quat_from_angle_axis(r0 * PI_F, f3{0.0f, 0.0f, 1.0f}));
-}
-
-// :506-522 reset_target_pose for environment e, executed by one lane
-__device__ __forceinline__ void reset_target_pose(const igx_allegro_params &p, const igx_allegro_buffers &b, int64_t e,
-                                                  float r0, float r1)
-{
-    const f4 rot = randomize_rotation(r0, r1);
-    float *gs = b.goal_states + e * 13;
-    const float *gi = b.goal_init_state + e * 13;
-    float *row = b.root_state_tensor + b.goal_object_indices[e] * 13;
-    const float g0 = gi[0], g1 = gi[1], g2 = gi[2];
-    gs[0] = g0; gs[1] = g1; gs[2] = g2;
-    gs[3] = rot.x; gs[4] = rot.y; gs[5] = rot.z; gs[6] = rot.w;
-    row[0] = g0 + p.goal_displacement[0];
-    row[1] = g1 + p.goal_displacement[1];
-    row[2] = g2 + p.goal_displacement[2];
-    row[3] = rot.x; row[4] = rot.y; row[5] = rot.z; row[6] = rot.w;
-#pragma unroll
-    for (int i = 7; i < 13; ++i) row[i] = 0.0f;
-    b.reset_goal[e] = 0;
 }
 
 __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
@@ -140,20 +104,8 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
         const int64_t ee = base + src;
         if (lane == 0) {  // target pose again (inside reset_idx), then the object actor
             reset_target_pose(p, b, ee, allegro_draw(p, b, ee, 41), allegro_draw(p, b, ee, 42));
-            float *row = b.root_state_tensor + b.object_indices[ee] * 13;
-            const float *oi = b.object_init_state + ee * 13;
-            const float r0 = allegro_draw(p, b, ee, 4), r1 = allegro_draw(p, b, ee, 5), r2 = allegro_draw(p, b, ee, 6);
-            const float r3 = allegro_draw(p, b, ee, 7), r4 = allegro_draw(p, b, ee, 8);
-            row[0] = oi[0] + p.reset_position_noise * r0;
-            row[1] = oi[1] + p.reset_position_noise * r1;
-            row[2] = oi[2] + p.reset_position_noise * r2;
-            const f4 rot = p.ignore_z_rot ? randomize_rotation_pen(r3) : randomize_rotation(r3, r4);
-            row[3] = rot.x; row[4] = rot.y; row[5] = rot.z; row[6] = rot.w;
-#pragma unroll
-            for (int i = 7; i < 13; ++i) row[i] = 0.0f;
-            b.progress[ee] = 0;
-            b.reset[ee] = 0;
-            b.successes[ee] = 0.0f;
+            reset_object_row(p, b, ee, allegro_draw(p, b, ee, 4), allegro_draw(p, b, ee, 5), allegro_draw(p, b, ee, 6),
+                             allegro_draw(p, b, ee, 7), allegro_draw(p, b, ee, 8));
         }
         if (lane < AD) {  // hand joints: lane j = joint j
             const int j = lane;
@@ -170,17 +122,7 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
     wave_sync();
 
     // ---- action path over the tile's slab (chunk k: env k/4, joints 4(k%4)..)
-    auto target = [&](float a, float prev, float lo, float hi) {
-        float c;
-        if (p.use_relative_control) {
-            c = tensor_clamp(prev + p.dof_speed_scale_dt * a, lo, hi);
-        } else {
-            c = scale(a, lo, hi);
-            c = p.act_moving_average * c + p.one_minus_act_moving_average * prev;
-            c = tensor_clamp(c, lo, hi);
-        }
-        return c;
-    };
+    auto target = [&](float a, float prev, float lo, float hi) { return joint_target(p, a, prev, lo, hi); };
     if (nvalid == WAVE) {
         v4f act[AD / 4];
         load_chunks<WAVE * AD / 4>(b.actions + base * AD, act, lane);
@@ -207,24 +149,6 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
     }
 }
 
-struct AllegroWorkspace {
-    unsigned long long num_resets;
-    double finished;
-};
-// Workspace records: 0 = the reduced sums of the last call, 1.. = one record per tile.
-constexpr int WS_RESULT = 0, WS_TILES = 1;
-
-// :714-719 from the two global sums
-__device__ __forceinline__ void update_consecutive_successes(const igx_allegro_params &p, const igx_allegro_buffers &b,
-                                                             unsigned long long num_resets, double finished)
-{
-    const float fin = (float)finished;
-    if (num_resets > 0) {
-        const float cons = b.consecutive_successes[0];
-        b.consecutive_successes[0] = p.av_factor * fin / (float)(long long)num_resets + p.one_minus_av_factor * cons;
-    }
-}
-
 // T environments per tile (one wavefront each)
 template <int OBS, bool REWARD, int T>
 __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
@@ -244,52 +168,20 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
     if (lane < 2 * AD) s_lim[lane] = lane < AD ? p.dof_lower[lane] : p.dof_upper[lane - AD];
 
     // ---- loads
-    int64_t prog = 0, rst = 0, rg = 0, rnd = 0;
-    float succ = 0.0f;
+    HandFlags fl{0, 0, 0, 0.0f};
+    int64_t rnd = 0;
     float obj[13], goal[7];
     v4f r_dof[T * AD * 2 / 4 / WAVE], r_force[T * AD / 4 / WAVE], r_act[T * AD / 4 / WAVE];
     v4f r_goal[(T * 13 / 4 + WAVE - 1) / WAVE];
-    if (live) {
-        if (REWARD) {
-            prog = ld_stream(b.progress + e);
-            rst = ld_stream(b.reset + e);
-            rg = ld_stream(b.reset_goal + e);
-            succ = ld_stream(b.successes + e);
-            if (b.randomize) rnd = ld_stream(b.randomize + e);
-        }
+    if (live && REWARD) {
+        fl.prog = ld_stream(b.progress + e);
+        fl.rst = ld_stream(b.reset + e);
+        fl.rg = ld_stream(b.reset_goal + e);
+        fl.succ = ld_stream(b.successes + e);
+        if (b.randomize) rnd = ld_stream(b.randomize + e);
     }
-    // ---- object rows.  When the tile's actor indices are evenly spaced (index = first + s * lane,
-    // the layout every env-major simulator produces), the window of root-state rows they span is
-    // streamed as whole lines and the rows are picked out of LDS; any other index pattern is gathered
-    // row by row (three 16-byte loads at a 4-byte-aligned address and one scalar per lane).
-    constexpr int MAX_S = (T * NOBS / 13 - 1) / (T - 1) < 4 ? (T * NOBS / 13 - 1) / (T - 1) : 4;
-    constexpr int WIN_IT = (((MAX_S * (T - 1) + 1) * 13 + 3) / 4 + WAVE - 1) / WAVE;
-    const int64_t oidx = live ? b.object_indices[e] : 0;
-    const int64_t oidx0 = __shfl(oidx, 0);
-    const int64_t ostride = __shfl(oidx, 1) - oidx0;
-    const bool windowed = full && ostride >= 1 && ostride <= MAX_S &&
-                          __ballot(lane >= T || oidx == oidx0 + ostride * lane) == ~0ull;
-    const int win_floats = windowed ? ((int)ostride * (T - 1) + 1) * 13 : 0;
-    const float *win = b.root_state_tensor + oidx0 * 13;
-    v4f r_win[WIN_IT];
-    float r_win_tail = 0.0f;
-    if (windowed) {
-#pragma unroll
-        for (int it = 0; it < WIN_IT; ++it) {
-            const int k = lane + it * WAVE;
-            if (4 * k + 4 <= win_floats) r_win[it] = ld_stream_u(win + 4 * k);
-        }
-        // the last one to three floats of the window; reading a whole chunk there could leave the tensor
-        const int tail0 = win_floats & ~3;
-        if (tail0 + lane < win_floats) r_win_tail = __builtin_nontemporal_load(win + tail0 + lane);
-    } else if (live) {
-        const float *orow = b.root_state_tensor + oidx * 13;
-        const v4f o0 = ld_stream_u(orow), o1 = ld_stream_u(orow + 4), o2 = ld_stream_u(orow + 8);
-        obj[0] = o0.x; obj[1] = o0.y; obj[2] = o0.z; obj[3] = o0.w;
-        obj[4] = o1.x; obj[5] = o1.y; obj[6] = o1.z; obj[7] = o1.w;
-        obj[8] = o2.x; obj[9] = o2.y; obj[10] = o2.z; obj[11] = o2.w;
-        obj[12] = __builtin_nontemporal_load(orow + 12);
-    }
+    RowWindow<T, T * NOBS> object_rows;
+    object_rows.load(b.root_state_tensor, b.object_indices, e, live, full, lane, obj);
     if (full) {
         load_chunks<T * AD * 2 / 4>(b.dof_state + base * (2 * AD), r_dof, lane);
         if (L::FORCE) load_chunks<T * AD / 4>(b.dof_force + base * AD, r_force, lane);
@@ -297,7 +189,7 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         load_chunks<T * 13 / 4>(b.goal_states + base * 13, r_goal, lane);
     }
 
-    // ---- goal rows: transpose through the (still empty) tile
+    // ---- goal rows, then the object rows of a windowed tile: transposed through the (still empty) tile
     park_rows<13, T>(r_goal, b.goal_states + base * 13, s_tile, nvalid, lane);
     wave_sync();
     if (live) {
@@ -305,22 +197,7 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         for (int i = 0; i < 7; ++i) goal[i] = s_tile[lane * 13 + i];
     }
     wave_sync();
-    if (windowed) {  // uniform over the wave: the window goes through the tile the same way
-#pragma unroll
-        for (int it = 0; it < WIN_IT; ++it) {
-            const int k = lane + it * WAVE;
-            if (4 * k + 4 <= win_floats) *reinterpret_cast<v4f *>(s_tile + 4 * k) = r_win[it];
-        }
-        const int tail0 = win_floats & ~3;
-        if (tail0 + lane < win_floats) s_tile[tail0 + lane] = r_win_tail;
-        wave_sync();
-        if (live) {
-            const float *orow = s_tile + (int)ostride * lane * 13;
-#pragma unroll
-            for (int i = 0; i < 13; ++i) obj[i] = orow[i];
-        }
-        wave_sync();
-    }
+    object_rows.pick(s_tile, live, lane, obj);
 
     // ---- stage pass-through columns
     if (full) {
@@ -350,8 +227,8 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
     wave_sync();
 
     // ---- per-env: pose columns and reward
-    int64_t resets = 0;
     float fin = 0.0f;
+    fl.rst = live ? fl.rst : 0;
     if (live) {
         float *row = s_tile + lane * NOBS;
         const f4 orot{obj[3], obj[4], obj[5], obj[6]};
@@ -371,113 +248,24 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         c[k + 7] = qd.x; c[k + 8] = qd.y; c[k + 9] = qd.z; c[k + 10] = qd.w;
 
         if (REWARD) {  // :663-719 compute_hand_reward
-            prog += 1;
             if (b.randomize) st_stream(b.randomize + e, rnd + 1);
-            const float goal_dist = norm3(f3{obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2]});
-            const float cc = fminf(norm3(f3{qd.x, qd.y, qd.z}), 1.0f);
-            const float rot_dist = 2.0f * asinf(cc);
-            const float dist_rew = goal_dist * p.dist_reward_scale;
-            const float rot_rew = 1.0f / (fabsf(rot_dist) + p.rot_eps) * p.rot_reward_scale;
             float act[AD], sq[AD];
             read_cols<AD, L::C_ACT, NOBS>(row, act);
 #pragma unroll
             for (int j = 0; j < AD; ++j) sq[j] = act[j] * act[j];
-            const float action_penalty = row_sum<AD>(sq);
-            float reward = dist_rew + rot_rew + action_penalty * p.action_penalty_scale;
-            // |rot_dist| <= success_tolerance, decided on the asin argument
-            const bool success = cc <= p.success_threshold_c;
-            const int64_t goal_resets = success ? 1 : rg;
-            succ = succ + (float)goal_resets;
-            if (goal_resets == 1) reward = reward + p.reach_goal_bonus;
-            resets = rst;
-            if (goal_dist >= p.fall_dist) {
-                reward = reward + p.fall_penalty;
-                resets = 1;
-            }
-            if (p.max_consecutive_successes > 0) {
-                if (success) prog = 0;
-                if (succ >= (float)p.max_consecutive_successes) resets = 1;
-            }
-            const bool timed_out = (float)prog >= p.max_episode_length_m1;
-            if (timed_out) resets = 1;
-            if (p.max_consecutive_successes > 0 && timed_out) reward = reward + 0.5f * p.fall_penalty;
+            const float reward = hand_reward(p, obj, goal, qd, row_sum<AD>(sq), fl, fin);
             st_stream(b.rew + e, reward);
-            st_stream(b.reset + e, resets);
-            st_stream(b.reset_goal + e, goal_resets);
-            st_stream(b.progress + e, prog);
-            st_stream(b.successes + e, succ);
-            fin = succ * (float)resets;
+            st_stream(b.reset + e, fl.rst);
+            st_stream(b.reset_goal + e, fl.rg);
+            st_stream(b.progress + e, fl.prog);
+            st_stream(b.successes + e, fl.succ);
         }
     }
     wave_sync();
     drain_rows<NOBS, T>(obs_out + base * NOBS, s_tile, nvalid, lane);
     if (REWARD && OBS == IGX_ALLEGRO_OBS_FULL_STATE && b.states)  // asymmetric observations: same 88 columns
         drain_rows<NOBS, T>(b.states + base * NOBS, s_tile, nvalid, lane);
-
-    if (REWARD) {  // this tile's partial sums -> its record
-        float f = fin;
-        long long cnt = resets;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            f += __shfl_xor(f, off);
-            cnt += __shfl_xor(cnt, off);
-        }
-        if (lane == 0) {
-            AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace) + WS_TILES + blockIdx.x;
-            ws->num_resets = (unsigned long long)cnt;
-            ws->finished = (double)f;
-        }
-    }
-}
-
-// The tiles' records are added in a fixed order (thread t takes records t, t + 1024, ...,
-// then a binary tree over the threads), so the sums do not depend on scheduling.
-// Result -> record 0 of the workspace; FINALIZE applies it to consecutive_successes.
-// (A last-tile-reduces scheme inside the step kernel was measured: the device-scope
-// release it needs on every tile costs six times the whole step.)
-template <bool FINALIZE>
-__global__ __launch_bounds__(1024) void allegro_reduce_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
-                                                              int64_t num_tiles)
-{
-    __shared__ unsigned long long s_cnt[1024];
-    __shared__ double s_fin[1024];
-    AllegroWorkspace *ws = reinterpret_cast<AllegroWorkspace *>(b.workspace);
-    const int t = threadIdx.x;
-    unsigned long long cnt = 0;
-    double fin = 0.0;
-    for (int64_t i = t; i < num_tiles; i += 1024) {
-        cnt += ws[WS_TILES + i].num_resets;
-        fin += ws[WS_TILES + i].finished;
-    }
-    s_cnt[t] = cnt;
-    s_fin[t] = fin;
-    __syncthreads();
-    for (int half = 512; half > 0; half >>= 1) {
-        if (t < half) {
-            s_cnt[t] += s_cnt[t + half];
-            s_fin[t] += s_fin[t + half];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        ws[WS_RESULT].num_resets = s_cnt[0];
-        ws[WS_RESULT].finished = s_fin[0];
-        if (FINALIZE) update_consecutive_successes(p, b, s_cnt[0], s_fin[0]);
-    }
-}
-
-// consecutive_successes from the records of all shards, added in index order, so every
-// rank of a sharded run computes the same bits
-__global__ void allegro_finalize_kernel(const igx_allegro_params p, const igx_allegro_buffers b,
-                                        const AllegroWorkspace *__restrict__ records, int num_records)
-{
-    unsigned long long num_resets = 0;
-    double finished = 0.0;
-    for (int i = 0; i < num_records; ++i) {
-        num_resets += records[i].num_resets;
-        finished += records[i].finished;
-    }
-    update_consecutive_successes(p, b, num_resets, finished);
+    if (REWARD) store_tile_record(b.workspace, fin, live ? fl.rst : 0, lane);
 }
 
 static int check_allegro(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n, bool post,
@@ -560,8 +348,12 @@ static int allegro_post_launch_t(const igx_allegro_params *p, const igx_allegro_
         if (rc != IGX_OK) return rc;
     }
     const int64_t tiles = (n + T - 1) / T;
-    if (finalize) hipLaunchKernelGGL(allegro_reduce_kernel<true>, dim3(1), dim3(1024), 0, s, *p, *b, tiles);
-    else hipLaunchKernelGGL(allegro_reduce_kernel<false>, dim3(1), dim3(1024), 0, s, *p, *b, tiles);
+    if (finalize)
+        hipLaunchKernelGGL((hand_reduce_kernel<igx_allegro_params, igx_allegro_buffers, true>), dim3(1), dim3(1024), 0, s, *p,
+                           *b, tiles);
+    else
+        hipLaunchKernelGGL((hand_reduce_kernel<igx_allegro_params, igx_allegro_buffers, false>), dim3(1), dim3(1024), 0, s, *p,
+                           *b, tiles);
     return launch_status("igx_allegro_post_physics(reduce)");
 }
 
@@ -601,7 +393,7 @@ extern "C" int igx_allegro_finalize_shards(const igx_allegro_params *p, const ig
     if (!records || !b->consecutive_successes)
         return fail(IGX_E_NULL, "igx_allegro_finalize_shards: records / consecutive_successes is NULL");
     if (!aligned16(records)) return fail(IGX_E_ALIGN, "igx_allegro_finalize_shards: records must be 16-byte aligned");
-    hipLaunchKernelGGL(allegro_finalize_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), *p, *b,
-                       static_cast<const AllegroWorkspace *>(records), (int)num_shards);
+    hipLaunchKernelGGL((hand_finalize_kernel<igx_allegro_params, igx_allegro_buffers>), dim3(1), dim3(1), 0,
+                       static_cast<hipStream_t>(stream), *p, *b, static_cast<const HandRecord *>(records), (int)num_shards);
     return launch_status("igx_allegro_finalize_shards");
 }

@@ -68,6 +68,32 @@ def allegro_finalize_shards(params, tensors, records):
     _lib.check(rc)
 
 
+# ---- ShadowHand ------------------------------------------------------------------------------
+def shadow_pre_physics(params, tensors, n_envs):
+    _lib.call_step("igx_shadow_pre_physics", params, _abi.ShadowBuffers, tensors, n_envs)
+
+
+def shadow_post_physics(params, tensors, n_envs):
+    _lib.call_step("igx_shadow_post_physics", params, _abi.ShadowBuffers, tensors, n_envs)
+
+
+def shadow_post_physics_shard(params, tensors, n_envs):
+    """One environment shard: leaves the 16-byte {num_resets, sum} record in tensors['workspace']."""
+    _lib.call_step("igx_shadow_post_physics_shard", params, _abi.ShadowBuffers, tensors, n_envs)
+
+
+def shadow_finalize_shards(params, tensors, records):
+    """records: contiguous device tensor of num_shards x 16 bytes, gathered in rank order."""
+    b, dev = _lib.make_buffers(_abi.ShadowBuffers, tensors)
+    nbytes = records.numel() * records.element_size()
+    if nbytes == 0 or nbytes % 16:
+        raise ValueError("records must hold a whole number of 16-byte shard records")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_shadow_finalize_shards(C.byref(params), C.byref(b), _lib.tensor_ptr(records),
+                                                   C.c_int32(nbytes // 16), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 def motion_tables(tensors):
     """igx_motion_tables from name -> device tensor (the caller keeps the tensors alive)."""
     t = _abi.MotionTables()

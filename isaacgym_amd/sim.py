@@ -60,6 +60,7 @@ _PHYSICS_OWNED = {
     "HumanoidImitate": ("root_states", "dof_state", "rigid_body_states"),
     "AllegroHand": ("dof_state", "dof_force", "root_state_tensor"),
     "HumanoidAMP": ("root_states", "dof_state", "rigid_body_state", "contact_forces"),
+    "ShadowHand": ("dof_state", "dof_force", "vec_sensor_tensor", "rigid_body_states", "root_state_tensor"),
 }
 
 
@@ -74,6 +75,8 @@ def _draw(task, n, seed, device, **kw):
         return synthetic.him_state(n, seed, device)
     if task == "AllegroHand":
         return synthetic.allegro_state(n, seed, device, kw.get("obs_type", "full_state"))
+    if task == "ShadowHand":
+        return synthetic.shadow_state(n, seed, device, kw.get("obs_type", "full_state"), kw.get("asymmetric", False))
     if task == "HumanoidAMP":
         return synthetic.amp_state(n, seed, device, kw.get("num_amp_obs_steps", 2))
     raise KeyError(task)
@@ -89,6 +92,7 @@ class SyntheticSim(TensorSim):
         first = _draw(task, num_envs, seed, self.device, **kw)
         self.tensors = dict(first)
         owned = _PHYSICS_OWNED[task]
+        owned = [k for k in owned if first.get(k) is not None]
         self._sets = [{k: first[k].clone() for k in owned}]
         for i in range(1, num_sets):
             nxt = _draw(task, num_envs, seed + 1000 * i, self.device, **kw)
@@ -102,6 +106,11 @@ class SyntheticSim(TensorSim):
         elif task == "HumanoidImitate":
             lo, hi = synthetic.him_limits()
             self.asset = dict(dof_limits_lower=lo, dof_limits_upper=hi, num_dof=_abi.IGX_HIM_DOF)
+        elif task == "ShadowHand":
+            p = synthetic.shadow_params()
+            self.asset = dict(dof_limits_lower=list(p.dof_lower), dof_limits_upper=list(p.dof_upper),
+                              num_dof=_abi.IGX_SHADOW_DOF, actuated_dof_indices=list(synthetic.SHADOW_ACTUATED),
+                              fingertip_handles=list(synthetic.SHADOW_FINGERTIPS))
         elif task == "AllegroHand":
             p = synthetic.allegro_params()
             self.asset = dict(dof_limits_lower=list(p.dof_lower), dof_limits_upper=list(p.dof_upper),

@@ -198,6 +198,83 @@ def allegro_state(n, seed, device, obs_type="full_state", asymmetric=False):
         workspace=torch.empty(allegro_workspace_floats(n), device=device))
 
 
+# ---------------------------------------------------------------- ShadowHand
+SHADOW_ACTUATED = [j for j in range(24) if j not in (5, 9, 13, 18)]   # the coupled distal finger joints are passive
+SHADOW_FINGERTIPS = [7, 11, 15, 20, 25]
+SHADOW_NUM_BODIES = 28
+
+
+def shadow_params(obs_type="full_state", seed=0, rng_offset=0, **over):
+    D = _abi.IGX_SHADOW_DOF
+    lo = [-0.3 - 0.02 * j for j in range(D)]
+    hi = [0.6 + 0.05 * j for j in range(D)]
+    kw = dict(obs_type=_abi.IGX_SHADOW_OBS[obs_type], max_consecutive_successes=0, ignore_z_rot=0,
+              use_relative_control=0, dist_reward_scale=-10.0, rot_reward_scale=1.0, rot_eps=0.1,
+              action_penalty_scale=-0.0002, success_tolerance=0.1, success_threshold_c=ALLEGRO_SUCCESS_C[0.1],
+              reach_goal_bonus=250.0, fall_dist=0.24, fall_penalty=0.0, max_episode_length_m1=599.0,
+              av_factor=0.1, one_minus_av_factor=1.0 - float(torch.tensor(0.1, dtype=torch.float32)),
+              vel_obs_scale=0.2, force_torque_obs_scale=10.0, reset_position_noise=0.01,
+              reset_dof_pos_noise=0.2, reset_dof_vel_noise=0.0, act_moving_average=1.0,
+              one_minus_act_moving_average=0.0, dof_speed_scale_dt=20.0 * 0.01667,
+              goal_displacement=[-0.2, -0.06, 0.12], num_bodies=SHADOW_NUM_BODIES, dof_lower=lo, dof_upper=hi,
+              actuated_dof_indices=SHADOW_ACTUATED, fingertip_handles=SHADOW_FINGERTIPS, seed=seed, rng_offset=rng_offset)
+    kw.update(over)
+    return _abi.ShadowParams(**kw)
+
+
+def shadow_state(n, seed, device, obs_type="full_state", asymmetric=False):
+    """name->tensor dict of igx_shadow_buffers, drawn like allegro_state."""
+    D, A, NB = _abi.IGX_SHADOW_DOF, _abi.IGX_SHADOW_ACTIONS, SHADOW_NUM_BODIES
+    gen = torch.Generator(device=device).manual_seed(seed)
+
+    def unit(q):
+        return q / q.norm(dim=-1, keepdim=True)
+
+    lo = torch.tensor([-0.3 - 0.02 * j for j in range(D)], device=device)
+    hi = torch.tensor([0.6 + 0.05 * j for j in range(D)], device=device)
+    dof_state = torch.empty(n, D, 2, device=device)
+    dof_state[..., 0] = lo + (hi - lo) * (torch.rand(n, D, generator=gen, device=device) * 1.04 - 0.02)
+    dof_state[..., 1] = torch.randn(n, D, generator=gen, device=device)
+    obj_init = torch.zeros(n, 13, device=device)
+    obj_init[:, 0:3] = torch.tensor([0.0, -0.39, 0.6], device=device) + 0.01 * torch.randn(n, 3, generator=gen, device=device)
+    obj_init[:, 6] = 1.0
+    goal_init = obj_init.clone()
+    goal_init[:, 2] -= 0.04
+    goal_states = goal_init.clone()
+    goal_states[:, 3:7] = unit(torch.randn(n, 4, generator=gen, device=device))
+    root = torch.zeros(3 * n, 13, device=device)
+    off = torch.randn(n, 3, generator=gen, device=device)
+    off = off / off.norm(dim=-1, keepdim=True) * (torch.rand(n, 1, generator=gen, device=device) * 0.3)
+    obj = torch.zeros(n, 13, device=device)
+    obj[:, 0:3] = goal_states[:, 0:3] + off
+    q = unit(torch.randn(n, 4, generator=gen, device=device))
+    near = torch.rand(n, generator=gen, device=device) < 0.01
+    q = torch.where(near.unsqueeze(-1), unit(goal_states[:, 3:7] + 0.02 * torch.randn(n, 4, generator=gen, device=device)), q)
+    obj[:, 3:7] = q
+    obj[:, 7:13] = torch.randn(n, 6, generator=gen, device=device)
+    idx = torch.arange(n, device=device, dtype=torch.int64)
+    root[3 * idx + 1] = obj
+    full = obs_type == "full_state" or asymmetric
+    return dict(
+        dof_state=dof_state, dof_force=torch.randn(n, D, generator=gen, device=device) if full else None,
+        vec_sensor_tensor=torch.randn(n, 30, generator=gen, device=device) if full else None,
+        rigid_body_states=torch.randn(n, NB, 13, generator=gen, device=device),
+        root_state_tensor=root, object_indices=3 * idx + 1, goal_object_indices=3 * idx + 2,
+        goal_states=goal_states, goal_init_state=goal_init, object_init_state=obj_init,
+        actions=torch.rand(n, A, generator=gen, device=device) * 2 - 1,
+        prev_targets=torch.zeros(n, D, device=device), cur_targets=torch.zeros(n, D, device=device),
+        obs=torch.zeros(n, _abi.IGX_SHADOW_NUM_OBS[obs_type], device=device),
+        states=torch.zeros(n, 211, device=device) if asymmetric else None,
+        rew=torch.zeros(n, device=device),
+        reset=(torch.rand(n, generator=gen, device=device) < 0.01).to(torch.int64),
+        reset_goal=(torch.rand(n, generator=gen, device=device) < 0.01).to(torch.int64),
+        progress=torch.randint(0, 600, (n,), generator=gen, device=device),
+        randomize=torch.zeros(n, dtype=torch.int64, device=device),
+        successes=torch.randint(0, 5, (n,), generator=gen, device=device).float(),
+        consecutive_successes=torch.zeros(1, device=device),
+        workspace=torch.empty(allegro_workspace_floats(n), device=device))
+
+
 # ---------------------------------------------------------------- HumanoidAMP
 def amp_params(num_amp_obs_steps=2, local_root_obs=False, enable_early_termination=True, max_episode_length=300):
     return _abi.AmpParams(num_amp_obs_steps=num_amp_obs_steps, local_root_obs=int(local_root_obs),

@@ -7,6 +7,7 @@ from .cartpole_sample import CartpoleSample
 from .humanoid import Humanoid
 from .humanoid_amp import HumanoidAMP
 from .humanoid_imitate import HumanoidImitate
+from .shadow_hand import ShadowHand
 
 isaacgym_task_map = {
     "AllegroHand": AllegroHand,
@@ -17,6 +18,7 @@ isaacgym_task_map = {
     "Humanoid": Humanoid,
     "HumanoidAMP": HumanoidAMP,
     "HumanoidImitate": HumanoidImitate,
+    "ShadowHand": ShadowHand,
 }
 
 
@@ -27,8 +29,10 @@ def make(name, num_envs, device="cuda:0", seed=0, sim=None, **env_overrides):
     cfg = task_config(name, num_envs, **env_overrides)
     if sim is None:
         extra = {}
-        if name == "AllegroHand":
+        if name in ("AllegroHand", "ShadowHand"):
             extra["obs_type"] = cfg["env"]["observationType"]
+        if name == "ShadowHand":
+            extra["asymmetric"] = cfg["env"]["asymmetric_observations"]
         if name == "HumanoidAMP":
             extra["num_amp_obs_steps"] = cfg["env"]["numAMPObsSteps"]
         sim = SyntheticSim(name, num_envs, device, seed=seed, **extra)

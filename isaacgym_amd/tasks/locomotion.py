@@ -35,6 +35,8 @@ class LocomotionTask(VecTask):
         env["numActions"] = self.NUM_ACTIONS
         super().__init__(cfg, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture,
                          force_render, sim=sim)
+        if self.randomize:  # create_sim: ant.py:143-144, humanoid.py:154-155
+            self.apply_randomizations(self.randomization_params)
         dev, n = self.device, self.num_envs
         self.num_dof = self.NUM_ACTIONS
         asset = self.sim.asset
@@ -121,6 +123,9 @@ class LocomotionTask(VecTask):
         self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
+        # ant.py:341-342, humanoid.py:362-363: reset_idx re-randomises, i.e. on steps where some env is reset
+        if self.randomize and bool(self.reset_buf.any()):
+            self.apply_randomizations(self.randomization_params)
         self._step_kernel(self._params(), self._buffers(), self.num_envs)
         if not self.HUMANOID:
             self.extras["true_objective"] = self._true_objective  # ant.py:332-337

@@ -870,6 +870,225 @@ def gen_allegro():
     _gen_allegro("ema", N=96, T=2, seed=9, act_moving_average=0.3)
 
 
+def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, object_type="block",
+                max_consecutive_successes=0, use_relative_control=False, act_moving_average=None):
+    """ShadowHand (tasks/shadow_hand.py): pre_physics_step (resets + targets of the 20 actuated joints)
+    and post_physics_step (observation layouts :473-584, compute_hand_reward :747-800) of the reference
+    class on synthetic simulator tensors."""
+    _install_gym_stubs()
+    mod = ref_shim.load("isaacgymenvs.tasks.shadow_hand")
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    cfg = _cfg("ShadowHand")
+    e = cfg["env"]
+
+    class Fake(mod.ShadowHand):
+        def __init__(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    t = Fake()
+    D, A, F, NB = 24, 20, 5, 28
+    t.cfg = cfg
+    t.device = "cpu"
+    t.num_envs = N
+    t.gym, t.sim, t.viewer, t.debug_viz = _Any(), None, None, False
+    t.randomize = False
+    for k_attr, k_cfg in (("dist_reward_scale", "distRewardScale"), ("rot_reward_scale", "rotRewardScale"),
+                          ("action_penalty_scale", "actionPenaltyScale"), ("success_tolerance", "successTolerance"),
+                          ("reach_goal_bonus", "reachGoalBonus"), ("fall_dist", "fallDistance"),
+                          ("fall_penalty", "fallPenalty"), ("rot_eps", "rotEps"),
+                          ("reset_position_noise", "resetPositionNoise"), ("reset_rotation_noise", "resetRotationNoise"),
+                          ("reset_dof_pos_noise", "resetDofPosRandomInterval"),
+                          ("reset_dof_vel_noise", "resetDofVelRandomInterval"),
+                          ("shadow_hand_dof_speed_scale", "dofSpeedScale"), ("max_episode_length", "episodeLength")):
+        setattr(t, k_attr, e[k_cfg])
+    t.vel_obs_scale = 0.2
+    t.force_torque_obs_scale = 10.0
+    t.force_scale = e.get("forceScale", 0.0)
+    t.use_relative_control = use_relative_control
+    t.act_moving_average = e["actionsMovingAverage"] if act_moving_average is None else act_moving_average
+    t.print_success_stat = False
+    t.max_consecutive_successes = max_consecutive_successes
+    t.av_factor = torch.tensor(e.get("averFactor", 0.1), dtype=torch.float)
+    t.object_type = object_type
+    t.obs_type = obs_type
+    t.asymmetric_obs = asymmetric
+    t.up_axis_idx = 2
+    t.dt = cfg["sim"]["dt"]
+    t.num_shadow_hand_dofs = D
+    t.num_actions = A
+    t.num_fingertips = F
+    t.extras = {}
+    nobs = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}[obs_type]
+    lo = -(torch.rand(D, generator=g) * 0.5 + 0.2)
+    hi = torch.rand(D, generator=g) * 1.2 + 0.3
+    t.shadow_hand_dof_lower_limits, t.shadow_hand_dof_upper_limits = lo, hi
+    t.shadow_hand_dof_default_pos = torch.zeros(D)
+    t.shadow_hand_dof_default_vel = torch.zeros(D)
+    t.shadow_hand_default_dof_pos = torch.zeros(D)
+    # the four coupled distal joints of the fingers are not actuated
+    actuated = [j for j in range(D) if j not in (5, 9, 13, 18)]
+    t.actuated_dof_indices = torch.tensor(actuated, dtype=torch.long)
+    t.fingertip_handles = torch.tensor([7, 11, 15, 20, 25], dtype=torch.long)
+    t.dof_state = torch.zeros(N * D, 2)
+    t.shadow_hand_dof_state = t.dof_state.view(N, -1, 2)[:, :D]
+    t.shadow_hand_dof_pos = t.shadow_hand_dof_state[..., 0]
+    t.shadow_hand_dof_vel = t.shadow_hand_dof_state[..., 1]
+    t.dof_force_tensor = torch.zeros(N, D)
+    t.vec_sensor_tensor = torch.zeros(N, 6 * F)
+    t.rigid_body_states = torch.zeros(N, NB, 13)
+    t.root_state_tensor = torch.zeros(3 * N, 13)
+    t.hand_indices = torch.arange(N) * 3
+    t.object_indices = torch.arange(N) * 3 + 1
+    t.goal_object_indices = torch.arange(N) * 3 + 2
+    t.object_init_state = torch.zeros(N, 13)
+    t.object_init_state[:, 0:3] = torch.tensor([0.0, -0.39, 0.6]) + 0.01 * torch.randn(N, 3, generator=g)
+    t.object_init_state[:, 6] = 1.0
+    t.goal_states = t.object_init_state.clone()
+    t.goal_states[:, 2] -= 0.04
+    t.goal_init_state = t.goal_states.clone()
+    t.goal_displacement_tensor = torch.tensor([-0.2, -0.06, 0.12])
+    t.prev_targets = torch.zeros(N, D)
+    t.cur_targets = torch.zeros(N, D)
+    t.x_unit_tensor = torch.tensor([1.0, 0.0, 0.0]).repeat(N, 1)
+    t.y_unit_tensor = torch.tensor([0.0, 1.0, 0.0]).repeat(N, 1)
+    t.z_unit_tensor = torch.tensor([0.0, 0.0, 1.0]).repeat(N, 1)
+    t.obs_buf = torch.zeros(N, nobs)
+    t.states_buf = torch.zeros(N, 211 if asymmetric else 0)
+    t.rew_buf = torch.zeros(N)
+    t.reset_buf = torch.ones(N, dtype=torch.long)
+    t.reset_goal_buf = t.reset_buf.clone()
+    t.progress_buf = torch.zeros(N, dtype=torch.long)
+    t.randomize_buf = torch.zeros(N, dtype=torch.long)
+    t.successes = torch.zeros(N)
+    t.consecutive_successes = torch.zeros(1)
+    t.force_decay = torch.tensor(0.99)
+    t.force_prob_range = torch.tensor([0.001, 0.1])
+    t.random_force_prob = torch.zeros(N)
+    t.rb_forces = torch.zeros(N, NB, 3)
+    t.object_rb_handles = torch.tensor([26])
+    t.object_rb_masses = torch.tensor([0.1])
+
+    tol = t.success_tolerance * (2.0 if object_type == "pen" else 1.0)
+    cstar = success_threshold_c(tol)
+    keys = ["actions", "rand", "pre_dof_state", "pre_root", "pre_goal_states", "pre_prev_targets", "pre_cur_targets",
+            "pre_reset", "pre_reset_goal", "pre_progress", "pre_successes",
+            "in_dof_state", "in_dof_force", "in_sensors", "in_bodies", "in_root", "obs", "states", "rew", "reset",
+            "reset_goal", "progress", "successes", "consecutive_successes", "randomize"]
+    rec = {k: [] for k in keys}
+    init = {"dof_lower": lo.numpy().copy(), "dof_upper": hi.numpy().copy(),
+            "object_init_state": t.object_init_state.numpy().copy(),
+            "goal_init_state": t.goal_init_state.numpy().copy(),
+            "goal_states0": t.goal_states.numpy().copy(), "root0": t.root_state_tensor.numpy().copy(),
+            "object_indices": t.object_indices.numpy().copy(),
+            "goal_object_indices": t.goal_object_indices.numpy().copy(),
+            "actuated_dof_indices": np.array(actuated, np.int32),
+            "fingertip_handles": t.fingertip_handles.numpy().astype(np.int32)}
+    R = 61
+    torch.manual_seed(seed + 100)
+    for step in range(T):
+        if step == 1:  # a few envs near the end of the episode
+            L = t.max_episode_length
+            t.progress_buf[:4] = torch.tensor([L - 4, L - 3, L - 2, L - 1])
+        actions = torch.rand(N, A, generator=g) * 2 - 1
+        rec["actions"].append(actions.numpy().copy())
+        env_ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        goal_ids = t.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
+        st = torch.get_rng_state()
+        t.pre_physics_step(actions)
+        dense = np.zeros((N, R), np.float32)
+        shapes = []
+        if len(goal_ids) > 0:
+            shapes.append((len(goal_ids), 4))
+        if len(env_ids) > 0:
+            shapes += [(len(env_ids), 2 * D + 5), (len(env_ids), 4), (len(env_ids),)]
+        draws = _replay_uniforms(st, shapes)
+        k = 0
+        if len(goal_ids) > 0:
+            dense[goal_ids.numpy(), 0:4] = draws[k].numpy()
+            k += 1
+        if len(env_ids) > 0:
+            dense[env_ids.numpy(), 4:4 + 2 * D + 5] = draws[k].numpy()
+            dense[env_ids.numpy(), 4 + 2 * D + 5:R] = draws[k + 1].numpy()
+        rec["rand"].append(dense)
+        rec["pre_dof_state"].append(t.dof_state.numpy().copy())
+        rec["pre_root"].append(t.root_state_tensor.numpy().copy())
+        rec["pre_goal_states"].append(t.goal_states.numpy().copy())
+        rec["pre_prev_targets"].append(t.prev_targets.numpy().copy())
+        rec["pre_cur_targets"].append(t.cur_targets.numpy().copy())
+        rec["pre_reset"].append(t.reset_buf.numpy().copy())
+        rec["pre_reset_goal"].append(t.reset_goal_buf.numpy().copy())
+        rec["pre_progress"].append(t.progress_buf.numpy().copy())
+        rec["pre_successes"].append(t.successes.numpy().copy())
+
+        # "physics": new joint state, joint forces, sensors, body states and object state
+        u = torch.rand(N, D, generator=g) * 1.04 - 0.02
+        t.dof_state.view(N, D, 2)[..., 0] = lo + (hi - lo) * u
+        t.dof_state.view(N, D, 2)[..., 1] = torch.randn(N, D, generator=g)
+        t.dof_force_tensor = torch.randn(N, D, generator=g)
+        t.vec_sensor_tensor = torch.randn(N, 6 * F, generator=g)
+        t.rigid_body_states = torch.randn(N, NB, 13, generator=g)
+        obj = torch.zeros(N, 13)
+        off = torch.randn(N, 3, generator=g)
+        off = off / off.norm(dim=-1, keepdim=True) * (torch.rand(N, 1, generator=g) * 0.3)
+        obj[:, 0:3] = t.goal_states[:, 0:3] + off
+        q = torch.randn(N, 4, generator=g)
+        q = q / q.norm(dim=-1, keepdim=True)
+        # envs [8, 8+N/8): object within ~0.12 rad of the goal orientation, straddling the success
+        # threshold; envs [4, 8): exactly the goal orientation
+        m = N // 8
+        ang = 0.08 + 0.04 * torch.rand(m, generator=g) * (2.0 if object_type == "pen" else 1.0)
+        ax = torch.randn(m, 3, generator=g)
+        dq = tj.quat_from_angle_axis(ang, ax)
+        q[8:8 + m] = tj.quat_mul(dq, t.goal_states[8:8 + m, 3:7])
+        q[4:8] = t.goal_states[4:8, 3:7]
+        obj[:, 3:7] = q
+        obj[:, 7:13] = torch.randn(N, 6, generator=g)
+        t.root_state_tensor[t.object_indices] = obj
+        rec["in_dof_state"].append(t.dof_state.numpy().copy())
+        rec["in_dof_force"].append(t.dof_force_tensor.numpy().copy())
+        rec["in_sensors"].append(t.vec_sensor_tensor.numpy().copy())
+        rec["in_bodies"].append(t.rigid_body_states.numpy().copy())
+        rec["in_root"].append(t.root_state_tensor.numpy().copy())
+        t.post_physics_step()
+        rec["obs"].append(t.obs_buf.numpy().copy())
+        rec["states"].append(t.states_buf.numpy().copy())
+        rec["rew"].append(t.rew_buf.numpy().copy())
+        rec["reset"].append(t.reset_buf.numpy().copy())
+        rec["reset_goal"].append(t.reset_goal_buf.numpy().copy())
+        rec["progress"].append(t.progress_buf.numpy().copy())
+        rec["successes"].append(t.successes.numpy().copy())
+        rec["consecutive_successes"].append(t.consecutive_successes.numpy().copy())
+        rec["randomize"].append(t.randomize_buf.numpy().copy())
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(init)
+    av = float(t.av_factor.item())
+    out["meta"] = _meta(task="ShadowHand", variant=name, N=N, T=T, seed=seed, obs_type=obs_type,
+                        asymmetric=asymmetric, object_type=object_type, num_bodies=NB,
+                        max_consecutive_successes=max_consecutive_successes,
+                        use_relative_control=use_relative_control,
+                        dist_reward_scale=t.dist_reward_scale, rot_reward_scale=t.rot_reward_scale,
+                        rot_eps=t.rot_eps, action_penalty_scale=t.action_penalty_scale,
+                        success_tolerance=tol, success_threshold_c=cstar,
+                        reach_goal_bonus=float(t.reach_goal_bonus), fall_dist=t.fall_dist,
+                        fall_penalty=t.fall_penalty, max_episode_length=t.max_episode_length,
+                        av_factor=av, one_minus_av_factor=1.0 - av,
+                        reset_position_noise=t.reset_position_noise, reset_dof_pos_noise=t.reset_dof_pos_noise,
+                        reset_dof_vel_noise=t.reset_dof_vel_noise, act_moving_average=float(t.act_moving_average),
+                        dof_speed_scale_dt=t.shadow_hand_dof_speed_scale * t.dt)
+    np.savez_compressed(os.path.join(OUT, "shadow_%s.npz" % name), **out)
+    print("shadow_%s.npz" % name, "N", N, "T", T, "c*", cstar,
+          "successes", int(out["reset_goal"].sum()), "resets", int(out["reset"].sum()))
+
+
+def gen_shadow():
+    _gen_shadow("default", N=70, T=3, seed=14)                       # full_state, 211 columns
+    _gen_shadow("openai_asym", N=70, T=2, seed=15, obs_type="openai", asymmetric=True)
+    _gen_shadow("full", N=70, T=2, seed=16, obs_type="full", use_relative_control=True)
+    _gen_shadow("no_vel_pen", N=70, T=3, seed=17, obs_type="full_no_vel", object_type="pen",
+                max_consecutive_successes=2, act_moving_average=0.3)
+
+
 # --------------------------------------------------------------------------
 AMP_NODE_NAMES = ["pelvis", "torso", "head", "right_upper_arm", "right_lower_arm", "right_hand",
                   "left_upper_arm", "left_lower_arm", "left_hand", "right_thigh", "right_shin", "right_foot",
@@ -1398,7 +1617,7 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -874,6 +874,216 @@ int orc_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_b
     return 0;
 }
 
+/* -------------------------------------------------------- ShadowHand --- */
+/* tasks/shadow_hand.py:586-602 reset_target_pose for one env */
+static void shadow_reset_target_pose(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t e, float r0, float r1)
+{
+    float rot[4];
+    randomize_rotation(r0, r1, rot); /* :803-806, the same function as AllegroHand's */
+    float *gs = b->goal_states + e * 13;
+    const float *gi = b->goal_init_state + e * 13;
+    for (int i = 0; i < 3; ++i) gs[i] = gi[i];
+    for (int i = 0; i < 4; ++i) gs[3 + i] = rot[i];
+    float *row = b->root_state_tensor + b->goal_object_indices[e] * 13;
+    for (int i = 0; i < 3; ++i) row[i] = gs[i] + p->goal_displacement[i];
+    for (int i = 0; i < 4; ++i) row[3 + i] = rot[i];
+    for (int i = 7; i < 13; ++i) row[i] = 0.0f;
+    b->reset_goal[e] = 0;
+}
+
+/* tasks/shadow_hand.py:670-698 pre_physics_step (+ :604-668 reset_idx).  Draws of an environment:
+ * [0,4) the goal-only reset_target_pose, [4,57) the 53 floats of reset_idx, [57,61) its inner
+ * reset_target_pose (torch draws them in the order 53, 4). */
+int orc_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n)
+{
+    const int D = IGX_SHADOW_DOF, A = IGX_SHADOW_ACTIONS, R = IGX_SHADOW_RAND_PER_ENV;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        const int rst = b->reset[e] != 0, rg = b->reset_goal[e] != 0;
+        float r[IGX_SHADOW_RAND_PER_ENV];
+        if (rst || rg)
+            for (int k = 0; k < R; ++k) r[k] = 2.0f * draw(b->rand, e, R, k, p->seed, p->rng_offset) + (-1.0f);
+        if (rg) shadow_reset_target_pose(p, b, e, r[0], r[1]);
+        if (rst) {
+            const float *rf = r + 4;
+            shadow_reset_target_pose(p, b, e, r[57], r[58]);
+            float *row = b->root_state_tensor + b->object_indices[e] * 13;
+            const float *oi = b->object_init_state + e * 13;
+            for (int i = 0; i < 13; ++i) row[i] = oi[i];
+            row[0] = oi[0] + p->reset_position_noise * rf[0];
+            row[1] = oi[1] + p->reset_position_noise * rf[1];
+            row[2] = oi[2] + p->reset_position_noise * rf[2]; /* up_axis_idx = 2 */
+            float rot[4];
+            if (p->ignore_z_rot) randomize_rotation_pen(rf[3], rot);
+            else randomize_rotation(rf[3], rf[4], rot);
+            for (int i = 0; i < 4; ++i) row[3 + i] = rot[i];
+            for (int i = 7; i < 13; ++i) row[i] = 0.0f;
+            for (int j = 0; j < D; ++j) { /* default pos / vel are zero (:163, shadow_hand_dof_default_vel) */
+                float delta_max = p->dof_upper[j] - 0.0f, delta_min = p->dof_lower[j] - 0.0f;
+                float rand_delta = delta_min + (delta_max - delta_min) * 0.5f * (rf[5 + j] + 1.0f);
+                float pos = 0.0f + p->reset_dof_pos_noise * rand_delta;
+                b->dof_state[(e * D + j) * 2] = pos;
+                b->dof_state[(e * D + j) * 2 + 1] = 0.0f + p->reset_dof_vel_noise * rf[5 + D + j];
+                b->prev_targets[e * D + j] = pos;
+                b->cur_targets[e * D + j] = pos;
+            }
+            b->progress[e] = 0;
+            b->reset[e] = 0;
+            b->successes[e] = 0.0f;
+        }
+        for (int a = 0; a < A; ++a) { /* :684-697, actuated joints only */
+            const int j = p->actuated_dof_indices[a];
+            float x = b->actions[e * A + a], lo = p->dof_lower[j], hi = p->dof_upper[j], c;
+            if (p->use_relative_control) {
+                c = b->prev_targets[e * D + j] + p->dof_speed_scale_dt * x;
+                c = fmaxf(fminf(c, hi), lo);
+            } else {
+                c = 0.5f * (x + 1.0f) * (hi - lo) + lo;
+                c = p->act_moving_average * c + p->one_minus_act_moving_average * b->prev_targets[e * D + j];
+                c = fmaxf(fminf(c, hi), lo);
+            }
+            b->cur_targets[e * D + j] = c;
+            b->prev_targets[e * D + j] = c;
+        }
+    }
+    return 0;
+}
+
+static int shadow_num_obs(int obs_type)
+{
+    return obs_type == IGX_SHADOW_OBS_OPENAI ? 42 : obs_type == IGX_SHADOW_OBS_FULL_NO_VEL ? 77
+         : obs_type == IGX_SHADOW_OBS_FULL ? 157 : 211;
+}
+
+/* tasks/shadow_hand.py:473-584: one observation row in the given layout */
+static void shadow_obs_row(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t e, int obs_type,
+                           const float *obj, const float *goal, const float qd[4], float *o)
+{
+    const int D = IGX_SHADOW_DOF, A = IGX_SHADOW_ACTIONS, F = IGX_SHADOW_FINGERTIPS;
+    const float *ds = b->dof_state + e * D * 2;
+    const float *bodies = b->rigid_body_states + e * (int64_t)p->num_bodies * 13;
+    int c = 0;
+    if (obs_type == IGX_SHADOW_OBS_OPENAI) { /* :481-485 */
+        for (int f = 0; f < F; ++f)
+            for (int i = 0; i < 3; ++i) o[c++] = bodies[p->fingertip_handles[f] * 13 + i];
+        for (int i = 0; i < 3; ++i) o[c++] = obj[i];
+        for (int i = 0; i < 4; ++i) o[c++] = qd[i];
+        for (int a = 0; a < A; ++a) o[c++] = b->actions[e * A + a];
+        return;
+    }
+    const int vel = obs_type != IGX_SHADOW_OBS_FULL_NO_VEL, full_state = obs_type == IGX_SHADOW_OBS_FULL_STATE;
+    for (int j = 0; j < D; ++j) o[c++] = unscale1(ds[2 * j], p->dof_lower[j], p->dof_upper[j]);
+    if (vel)
+        for (int j = 0; j < D; ++j) o[c++] = p->vel_obs_scale * ds[2 * j + 1];
+    if (full_state)
+        for (int j = 0; j < D; ++j) o[c++] = p->force_torque_obs_scale * b->dof_force[e * D + j];
+    for (int i = 0; i < 7; ++i) o[c++] = obj[i];
+    if (vel) {
+        for (int i = 0; i < 3; ++i) o[c++] = obj[7 + i];
+        for (int i = 0; i < 3; ++i) o[c++] = p->vel_obs_scale * obj[10 + i];
+    }
+    for (int i = 0; i < 7; ++i) o[c++] = goal[i];
+    for (int i = 0; i < 4; ++i) o[c++] = qd[i];
+    for (int f = 0; f < F; ++f) /* fingertip state (13) or position (3), unscaled */
+        for (int i = 0; i < (vel ? 13 : 3); ++i) o[c++] = bodies[p->fingertip_handles[f] * 13 + i];
+    if (full_state)
+        for (int k = 0; k < 6 * F; ++k) o[c++] = p->force_torque_obs_scale * b->vec_sensor_tensor[e * 6 * F + k];
+    for (int a = 0; a < A; ++a) o[c++] = b->actions[e * A + a];
+}
+
+/* tasks/shadow_hand.py:710-715 post_physics_step, :437-471 compute_observations, :747-800 compute_hand_reward */
+static int shadow_post(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n, allegro_record *rec)
+{
+    const int A = IGX_SHADOW_ACTIONS;
+    const int nobs = shadow_num_obs(p->obs_type);
+    int64_t num_resets = 0;
+    double fin = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : num_resets, fin)
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t prog = b->progress[e] + 1;
+        if (b->randomize) b->randomize[e] += 1;
+        const float *obj = b->root_state_tensor + b->object_indices[e] * 13;
+        const float *goal = b->goal_states + e * 13;
+        float gconj[4], qd[4];
+        quat_conjugate(goal + 3, gconj);
+        quat_mul(obj + 3, gconj, qd);
+        shadow_obs_row(p, b, e, p->obs_type, obj, goal, qd, b->obs + e * nobs);
+        if (b->states) shadow_obs_row(p, b, e, IGX_SHADOW_OBS_FULL_STATE, obj, goal, qd, b->states + e * 211);
+
+        float dpos[3] = { obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2] };
+        float goal_dist = norm3(dpos);
+        float cc = fminf(norm3(qd), 1.0f);
+        float rot_dist = 2.0f * asinf(cc);
+        float dist_rew = goal_dist * p->dist_reward_scale;
+        float rot_rew = 1.0f / (fabsf(rot_dist) + p->rot_eps) * p->rot_reward_scale;
+        float sq[IGX_SHADOW_ACTIONS];
+        for (int a = 0; a < A; ++a) sq[a] = b->actions[e * A + a] * b->actions[e * A + a];
+        float action_penalty = row_sum(sq, A);
+        float reward = dist_rew + rot_rew + action_penalty * p->action_penalty_scale;
+        int success = cc <= p->success_threshold_c;
+        int64_t goal_resets = success ? 1 : b->reset_goal[e];
+        float successes = b->successes[e] + (float)goal_resets;
+        if (goal_resets == 1) reward = reward + p->reach_goal_bonus;
+        int64_t resets = b->reset[e];
+        if (goal_dist >= p->fall_dist) {
+            reward = reward + p->fall_penalty;
+            resets = 1;
+        }
+        if (p->max_consecutive_successes > 0) {
+            if (success) prog = 0;
+            if (successes >= (float)p->max_consecutive_successes) resets = 1;
+        }
+        int timed_out = (float)prog >= p->max_episode_length_m1;
+        if (timed_out) resets = 1;
+        if (p->max_consecutive_successes > 0 && timed_out) reward = reward + 0.5f * p->fall_penalty;
+
+        b->rew[e] = reward;
+        b->reset[e] = resets;
+        b->reset_goal[e] = goal_resets;
+        b->progress[e] = prog;
+        b->successes[e] = successes;
+        num_resets += resets;
+        fin += (double)(successes * (float)resets);
+    }
+    rec->num_resets = (uint64_t)num_resets;
+    rec->finished = fin;
+    return 0;
+}
+
+static void shadow_finalize(const igx_shadow_params *p, const igx_shadow_buffers *b, const allegro_record *recs, int count)
+{
+    uint64_t num_resets = 0;
+    double fin = 0.0;
+    for (int i = 0; i < count; ++i) {
+        num_resets += recs[i].num_resets;
+        fin += recs[i].finished;
+    }
+    if (num_resets > 0) {
+        float f = (float)fin;
+        b->consecutive_successes[0] =
+            p->av_factor * f / (float)(int64_t)num_resets + p->one_minus_av_factor * b->consecutive_successes[0];
+    }
+}
+
+int orc_shadow_post_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n)
+{
+    allegro_record rec;
+    shadow_post(p, b, n, &rec);
+    shadow_finalize(p, b, &rec, 1);
+    return 0;
+}
+
+int orc_shadow_post_physics_shard(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n)
+{
+    return shadow_post(p, b, n, (allegro_record *)b->workspace);
+}
+
+int orc_shadow_finalize_shards(const igx_shadow_params *p, const igx_shadow_buffers *b, const void *records, int32_t num_shards)
+{
+    shadow_finalize(p, b, (const allegro_record *)records, num_shards);
+    return 0;
+}
+
 /* ------------------------------------------ AMP motion library / obs --- */
 /* tasks/amp/humanoid_amp_base.py:43-44 */
 static const int DOF_BODY_IDS[12] = { 1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 13, 14 };

@@ -108,6 +108,26 @@ def allegro_finalize_shards(params, bufs, records):
                                              C.c_int32(records.shape[0])) == 0
 
 
+# ---- ShadowHand --------------------------------------------------------------
+def shadow_pre_physics(params, bufs, n):
+    _call(lib().orc_shadow_pre_physics, params, _abi.ShadowBuffers, bufs, n)
+
+
+def shadow_post_physics(params, bufs, n):
+    _call(lib().orc_shadow_post_physics, params, _abi.ShadowBuffers, bufs, n)
+
+
+def shadow_post_physics_shard(params, bufs, n):
+    _call(lib().orc_shadow_post_physics_shard, params, _abi.ShadowBuffers, bufs, n)
+
+
+def shadow_finalize_shards(params, bufs, records):
+    records = np.ascontiguousarray(records, np.uint8)
+    b = _abi.make_buffers(_abi.ShadowBuffers, bufs, _np_ptr)
+    assert lib().orc_shadow_finalize_shards(C.byref(params), C.byref(b), C.c_void_p(records.ctypes.data),
+                                            C.c_int32(records.shape[0])) == 0
+
+
 # ---- AMP motion library / observations ------------------------------------
 def motion_tables(tabs):
     """tabs: dict of numpy arrays named like igx_motion_tables fields."""

@@ -187,6 +187,99 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
 
+SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen"]
+
+
+def shadow_params(meta, g, seed=0, rng_offset=0):
+    ama = meta["act_moving_average"]
+    return _abi.ShadowParams(
+        obs_type=_abi.IGX_SHADOW_OBS[meta["obs_type"]],
+        max_consecutive_successes=meta["max_consecutive_successes"],
+        ignore_z_rot=1 if meta["object_type"] == "pen" else 0,
+        use_relative_control=1 if meta["use_relative_control"] else 0,
+        dist_reward_scale=meta["dist_reward_scale"], rot_reward_scale=meta["rot_reward_scale"],
+        rot_eps=meta["rot_eps"], action_penalty_scale=meta["action_penalty_scale"],
+        success_tolerance=meta["success_tolerance"], success_threshold_c=meta["success_threshold_c"],
+        reach_goal_bonus=meta["reach_goal_bonus"], fall_dist=meta["fall_dist"], fall_penalty=meta["fall_penalty"],
+        max_episode_length_m1=float(meta["max_episode_length"] - 1),
+        av_factor=meta["av_factor"], one_minus_av_factor=meta["one_minus_av_factor"],
+        vel_obs_scale=0.2, force_torque_obs_scale=10.0,
+        reset_position_noise=meta["reset_position_noise"], reset_dof_pos_noise=meta["reset_dof_pos_noise"],
+        reset_dof_vel_noise=meta["reset_dof_vel_noise"],
+        act_moving_average=ama, one_minus_act_moving_average=1.0 - ama,
+        dof_speed_scale_dt=meta["dof_speed_scale_dt"], goal_displacement=[-0.2, -0.06, 0.12],
+        num_bodies=meta["num_bodies"], dof_lower=g["dof_lower"], dof_upper=g["dof_upper"],
+        actuated_dof_indices=[int(x) for x in g["actuated_dof_indices"]],
+        fingertip_handles=[int(x) for x in g["fingertip_handles"]], seed=seed, rng_offset=rng_offset)
+
+
+def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
+    """Replay a ShadowHand golden file through pre_fn / post_fn (see allegro_replay)."""
+    m = g["meta"]
+    N, T, NB = m["N"], m["T"], m["num_bodies"]
+    p = shadow_params(m, g)
+    nobs = _abi.IGX_SHADOW_NUM_OBS[m["obs_type"]]
+    asym = bool(m["asymmetric"])
+    b = dict(dof_state=zeros((N, 24, 2), np.float32), dof_force=zeros((N, 24), np.float32),
+             vec_sensor_tensor=zeros((N, 30), np.float32), rigid_body_states=zeros((N, NB, 13), np.float32),
+             root_state_tensor=to_buf(g["root0"]), object_indices=to_buf(g["object_indices"]),
+             goal_object_indices=to_buf(g["goal_object_indices"]), goal_states=to_buf(g["goal_states0"]),
+             goal_init_state=to_buf(g["goal_init_state"]), object_init_state=to_buf(g["object_init_state"]),
+             actions=zeros((N, 20), np.float32), prev_targets=zeros((N, 24), np.float32),
+             cur_targets=zeros((N, 24), np.float32), rand=zeros((N, 61), np.float32),
+             obs=zeros((N, nobs), np.float32), states=zeros((N, 211), np.float32) if asym else None,
+             rew=zeros((N,), np.float32), reset=to_buf(np.ones(N, np.int64)), reset_goal=to_buf(np.ones(N, np.int64)),
+             progress=zeros((N,), np.int64), randomize=zeros((N,), np.int64), successes=zeros((N,), np.float32),
+             consecutive_successes=zeros((1,), np.float32), workspace=zeros((4 * ((N + 31) // 32 + 1),), np.float32))
+
+    def put(name, arr):
+        dst = b[name]
+        src = to_buf(np.ascontiguousarray(arr).reshape(tuple(dst.shape)))
+        if hasattr(dst, "copy_"):
+            dst.copy_(src)
+        else:
+            dst[...] = src
+
+    rot_cols = [3, 4, 5, 6]
+    L = m["max_episode_length"]
+    for t in range(T):
+        if t == 1:
+            prog = to_np(b["progress"]).copy()
+            prog[:4] = [L - 4, L - 3, L - 2, L - 1]
+            put("progress", prog)
+        put("actions", g["actions"][t])
+        put("rand", g["rand"][t])
+        pre_fn(p, b, N)
+        what = "pre step %d " % t
+        for k, ref in (("reset", g["pre_reset"][t]), ("reset_goal", g["pre_reset_goal"][t]),
+                       ("progress", g["pre_progress"][t])):
+            assert np.array_equal(to_np(b[k]), ref), what + k
+        for k, ref in (("dof_state", g["pre_dof_state"][t]), ("prev_targets", g["pre_prev_targets"][t]),
+                       ("cur_targets", g["pre_cur_targets"][t]), ("successes", g["pre_successes"][t])):
+            assert bit_equal_fraction(to_np(b[k]).reshape(ref.shape), ref) == 1.0, what + k
+        for k, ref in (("root_state_tensor", g["pre_root"][t]), ("goal_states", g["pre_goal_states"][t])):
+            got = to_np(b[k])
+            nonrot = [c for c in range(13) if c not in rot_cols]
+            assert bit_equal_fraction(got[:, nonrot], ref[:, nonrot]) == 1.0, what + k
+            assert_close(got[:, rot_cols], ref[:, rot_cols], what=what + k + " rot")
+        put("goal_states", g["pre_goal_states"][t])
+        put("dof_state", g["in_dof_state"][t])
+        put("dof_force", g["in_dof_force"][t])
+        put("vec_sensor_tensor", g["in_sensors"][t])
+        put("rigid_body_states", g["in_bodies"][t])
+        put("root_state_tensor", g["in_root"][t])
+        post_fn(p, b, N)
+        what = "post step %d " % t
+        for k in ("reset", "reset_goal", "progress", "randomize"):
+            assert np.array_equal(to_np(b[k]), g[k][t]), what + k
+        assert bit_equal_fraction(to_np(b["successes"]), g["successes"][t]) == 1.0, what + "successes"
+        assert_close(to_np(b["obs"]), g["obs"][t], what=what + "obs")
+        if asym:
+            assert_close(to_np(b["states"]), g["states"][t], what=what + "states")
+        assert_close(to_np(b["rew"]), g["rew"][t], what=what + "rew")
+        assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
+
+
 def assert_close_near_identity(x, ref, scale=1.0, rtol=RTOL, quantum=2e-2, max_frac=1e-4, what=""):
     """assert_close for quantities derived from quat_to_angle_axis(slerp(...)) of a
     nearly identity rotation.  fp32 slerp divides by sqrt(1 - c*c), which for close

@@ -46,6 +46,9 @@ int main(void){
   printf("LocoBuffers %zu\n", sizeof(igx_loco_buffers));
   printf("AllegroParams %zu\n", sizeof(igx_allegro_params));
   printf("AllegroBuffers %zu\n", sizeof(igx_allegro_buffers));
+  printf("ShadowParams %zu\n", sizeof(igx_shadow_params));
+  printf("ShadowBuffers %zu\n", sizeof(igx_shadow_buffers));
+  printf("off_shadow_seed %zu\n", offsetof(igx_shadow_params, seed));
   printf("MotionTables %zu\n", sizeof(igx_motion_tables));
   printf("MotionStateOut %zu\n", sizeof(igx_motion_state_out));
   printf("AmpParams %zu\n", sizeof(igx_amp_params));
@@ -69,6 +72,8 @@ int main(void){
         name, size = line.split()
         if name == "off_seed":
             assert _abi.AllegroParams.seed.offset == int(size)
+        elif name == "off_shadow_seed":
+            assert _abi.ShadowParams.seed.offset == int(size)
         elif name == "off_clip":
             assert _abi.VecTaskTail.clip_obs.offset == int(size)
         elif name == "off_noise":
@@ -94,7 +99,8 @@ def test_null_arguments_are_rejected_without_a_gpu():
 def test_every_entry_point_rejects_null_structs():
     lib = _lib.lib()
     for name in ("igx_cartpole_step", "igx_humanoid_step", "igx_allegro_pre_physics", "igx_allegro_post_physics",
-                 "igx_allegro_post_physics_shard", "igx_humanoid_amp_step"):
+                 "igx_allegro_post_physics_shard", "igx_humanoid_amp_step", "igx_shadow_pre_physics",
+                 "igx_shadow_post_physics", "igx_shadow_post_physics_shard"):
         assert getattr(lib, name)(None, None, 4, None) == _abi.IGX_E_NULL, name
     for name in ("igx_cartpole_reset", "igx_ant_reset", "igx_humanoid_reset"):
         assert getattr(lib, name)(None, None, None, 4, None) == _abi.IGX_E_NULL, name

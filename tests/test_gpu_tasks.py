@@ -331,3 +331,68 @@ def test_make_ant_imitate_runs():
     for _ in range(3):
         task.step(torch.zeros(5000, 8, device=DEV))
     assert task.pose_threshold >= 1.8 and int(task.progress_buf.max()) == 3
+
+
+# ------------------------------------------------------------------------- ShadowHand
+@pytest.mark.parametrize("obs_type,asym", [("full_state", False), ("openai", True), ("full", False), ("full_no_vel", False)])
+def test_shadow_class_equals_abi_calls(obs_type, asym):
+    n = 3000
+    task = tasks.make("ShadowHand", n, DEV, seed=4, observationType=obs_type, asymmetric_observations=asym)
+    assert task.obs_buf.shape == (n, {"full_state": 211, "full": 157, "full_no_vel": 77, "openai": 42}[obs_type])
+    assert task.states_buf.shape == (n, 211 if asym else 0) and task.num_actions == 20 and task.num_bodies == 28
+    ref = synthetic.shadow_state(n, 4, DEV, obs_type, asym)  # what the sim drew
+    ref["reset"] = torch.ones(n, dtype=torch.int64, device=DEV)
+    ref["reset_goal"] = torch.ones(n, dtype=torch.int64, device=DEV)
+    ref["progress"].zero_()
+    ref["successes"].zero_()
+    sets = [synthetic.shadow_state(n, 4, DEV, obs_type, asym), synthetic.shadow_state(n, 1004, DEV, obs_type, asym)]
+    for step in range(3):
+        act = torch.rand(n, 20, device=DEV) * 4 - 2   # clipActions 1.0 is applied by step()
+        obs_dict, rew, reset, extras = task.step(act)
+        p = synthetic.shadow_params(obs_type, seed=4, rng_offset=2 * step + 1, dof_speed_scale_dt=20.0 * task.dt)
+        ref["actions"] = torch.clamp(act, -1.0, 1.0)
+        ops.shadow_pre_physics(p, ref, n)
+        for k in ("dof_state", "dof_force", "vec_sensor_tensor", "rigid_body_states", "root_state_tensor"):
+            if ref[k] is not None:
+                ref[k].copy_(sets[(step + 1) % 2][k])  # controlFrequencyInv = 1: one simulate() per step
+        p.rng_offset = 2 * step + 2
+        ops.shadow_post_physics(p, ref, n)
+        for k, a in (("obs", task.obs_buf), ("rew", task.rew_buf), ("reset", task.reset_buf),
+                     ("reset_goal", task.reset_goal_buf), ("progress", task.progress_buf),
+                     ("successes", task.successes), ("consecutive_successes", task.consecutive_successes),
+                     ("cur_targets", task.cur_targets), ("prev_targets", task.prev_targets),
+                     ("goal_states", task.goal_states)):
+            assert torch.equal(a, ref[k]), "%s step %d" % (k, step)
+        if asym:
+            assert torch.equal(task.states_buf, ref["states"])
+            assert torch.equal(obs_dict["states"], torch.clamp(ref["states"], -5.0, 5.0))
+        assert torch.equal(obs_dict["obs"], torch.clamp(ref["obs"], -5.0, 5.0))
+        assert float(extras["consecutive_successes"]) == float(ref["consecutive_successes"])
+
+
+# ------------------------------------------------------------------------- task.randomize
+def test_ant_with_randomization_noise():
+    """task.randomize: the observation / action noise of randomization_params through the fused
+    action stage and step tail (draws made inside the kernels): the noised run differs from the plain
+    one by noise of the configured spread, and nothing else."""
+    n = 1 << 16
+    def build(randomize):
+        cfg = C.task_config("Ant", n)
+        cfg["task"]["randomize"] = randomize
+        return tasks.Ant(cfg, DEV, DEV, 0, True, False, False, sim=SyntheticSim("Ant", n, DEV, seed=9), seed=9)
+    plain, noisy = build(False), build(True)
+    act = torch.rand(n, 8, device=DEV) - 0.5
+    for step in range(3):
+        for t in (plain, noisy):
+            t.step(act)
+        assert "observations" in noisy.dr_randomizations and "actions" in noisy.dr_randomizations
+        da = (noisy.actions - plain.actions).flatten()
+        assert abs(float(da.mean())) < 5e-4 and abs(float(da.std()) - 0.02) < 1e-3    # range [0, 0.02], no correlated part
+        # observations of envs whose reset / reward decisions did not flip
+        same = (noisy.reset_buf == plain.reset_buf)
+        assert float(same.float().mean()) > 0.99
+    # last step: the stored obs_buf carries the observation noise on top of the (action-noised) observation
+    d = (noisy.obs_buf - plain.obs_buf)[same]
+    cols = d[:, :12]   # columns that do not depend on the actions
+    assert abs(float(cols.mean())) < 1e-4 and abs(float(cols.std()) - 0.002) < 2e-4
+    assert noisy.last_rand_step >= 0 and not noisy.first_randomization

@@ -67,6 +67,15 @@ def main():
         report("allegro_post", timed(lambda i: ops.allegro_post_physics(p, sets[i % 3], n), a.steps), BYTES["allegro_post"])
         report("allegro_pre", timed(lambda i: ops.allegro_pre_physics(p, sets[i % 3], n), a.steps), BYTES["allegro_pre"])
         del sets
+    if on("shadow"):
+        # full_state post: read dof_state 192 + dof_force 96 + sensors 120 + 5 fingertip rows 260 + object row 52 +
+        # goal pose 28 + actions 80 + flags 28 = 856; write obs 844 + rew 4 + flags 28 = 876
+        m = min(n, 1 << 19)
+        p = synthetic.shadow_params("full_state", 1, 0)
+        sets = [synthetic.shadow_state(m, s, DEV) for s in range(3)]
+        report("shadow_post", timed(lambda i: ops.shadow_post_physics(p, sets[i % 3], m), a.steps), 1732, units=m)
+        report("shadow_pre", timed(lambda i: ops.shadow_pre_physics(p, sets[i % 3], m), a.steps), 480, units=m)
+        del sets
     if on("amp"):
         for K in (2,):
             p = synthetic.amp_params(K)
