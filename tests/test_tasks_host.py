@@ -25,7 +25,7 @@ def test_default_configs_cover_the_task_map():
     c["env"]["resetDist"] = 9.0
     assert cfg.task_config("Cartpole")["env"]["resetDist"] == 3.0  # deep copies
     with pytest.raises(KeyError):
-        cfg.task_config("ShadowHand")
+        cfg.task_config("Trifinger")
 
 
 def test_tasks_refuse_a_cpu_pipeline():
