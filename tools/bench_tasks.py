@@ -116,6 +116,27 @@ def main():
         rst = torch.randint(0, 2, (n,), device=DEV)
         to = torch.zeros(n, dtype=torch.bool, device=DEV)
         report("tail_ant", timed(lambda i: ops.vec_task_tail(obs, out, 5.0, prog, rst, to, 1000), a.steps), BYTES["tail_ant"])
+    if on("prestep"):
+        # action stage (Ant: 8 actions): read 4 + write 4 + 4 per action; with noise + 4 (the kept draw)
+        sets = [(torch.randn(n, 8, device=DEV), torch.empty(n, 8, device=DEV), torch.empty(n, 8, device=DEV)) for _ in range(4)]
+        gain = torch.rand(8, device=DEV) * 100
+        def stage(i, **kw):
+            a, keep, f = sets[i % 4]
+            ops.action_stage(a, f, "force", gain=gain, power_scale=1.0, clip_actions=1.0, actions_out=keep, **kw)
+        report("action_stage_ant", timed(stage, a.steps), 96)
+        corr = [torch.randn(n, 8, device=DEV) for _ in range(4)]
+        specs = [ops.NoiseSpec(c, 0.0, 0.0, 0.02, 0.0, "additive", "gaussian", seed=1) for c in corr]
+        report("action_stage_ant_noise", timed(lambda i: stage(i, noise=specs[i % 4]), a.steps), 128)
+        obs = [torch.randn(n, 60, device=DEV) for _ in range(4)]
+        out = torch.empty(n, 60, device=DEV)
+        oc = [torch.randn(n, 60, device=DEV) for _ in range(2)]
+        ospec = [ops.NoiseSpec(c, 0.001, 0.0, 0.002, 0.0, "additive", "gaussian", seed=2) for c in oc]
+        prog = torch.randint(0, 1000, (n,), device=DEV)
+        rst = torch.randint(0, 2, (n,), device=DEV)
+        to = torch.zeros(n, dtype=torch.bool, device=DEV)
+        # obs read + corr read + noised obs written back + clamped copy written = 16 B per element, + 17 B flags
+        report("tail_ant_noise", timed(lambda i: ops.vec_task_tail(obs[i % 4], out, 5.0, prog, rst, to, 1000, noise=ospec[i % 2],
+                                                                   obs_noised=obs[i % 4]), a.steps), 60 * 16 + 17)
     if on("motion"):
         sys.path.insert(0, ".")
         from tests import helpers as H
