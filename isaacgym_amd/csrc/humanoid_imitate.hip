@@ -2,8 +2,9 @@
 //
 // A wavefront owns a tile of 16 consecutive environments (13 KB of observation rows in
 // LDS; a 64-row tile would be 52 KB): the tile's contiguous slices of dof_state, root
-// rows, rigid-body rows and actions are streamed with coalesced 16-byte non-temporal
-// loads and scattered to their observation columns in LDS; flagged environments are
+// rows and actions are streamed with coalesced 16-byte non-temporal loads, the head of
+// every rigid-body row (its position) with one 16-byte load per row, and everything is
+// scattered to its observation column in LDS; flagged environments are
 // reset by the whole wave (lane j = joint j); four lanes share an environment for the
 // reward sums (fp64 where the fp64 motion frame enters, as in the reference); the rows
 // leave as one contiguous slab.
@@ -34,9 +35,9 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
     const bool full = nvalid == HT;
 
     // ---- loads, issued back to back
-    constexpr int DOF4 = HT * HD * 2 / 4, ROOT4 = HT * 13 / 4, BODY4 = HT * BODY_ROW / 4, ACT4 = HT * HD / 4;
-    v4f r_dof[(DOF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE], r_body[(BODY4 + WAVE - 1) / WAVE],
-        r_act[(ACT4 + WAVE - 1) / WAVE];
+    constexpr int DOF4 = HT * HD * 2 / 4, ROOT4 = HT * 13 / 4, ACT4 = HT * HD / 4;
+    constexpr int BODY_ROWS = HT * HB, BODY_IT = (BODY_ROWS + WAVE - 1) / WAVE;  // one lane per (env, body) row
+    v4f r_dof[(DOF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE], r_body[BODY_IT], r_act[(ACT4 + WAVE - 1) / WAVE];
     const int64_t ef = base + (lane < nvalid ? lane : 0);  // lanes 0..15 carry the per-env scalars
     int64_t prog = ld_stream(b.progress + ef);
     int64_t rst = ld_stream(b.reset + ef);
@@ -44,7 +45,13 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
     if (full) {
         load_chunks<DOF4>(b.dof_state + base * (2 * HD), r_dof, lane);
         load_chunks<ROOT4>(b.root_states + base * 13, r_root, lane);
-        load_chunks<BODY4>(b.rigid_body_states + base * BODY_ROW, r_body, lane);
+        // only the position of a body row is observed: one 16-byte load at the head of each 52-byte row
+        // (adjacent lanes take adjacent rows, so every line of the slab is still fetched exactly once)
+#pragma unroll
+        for (int it = 0; it < BODY_IT; ++it) {
+            const int q = lane + it * WAVE;
+            if (q < BODY_ROWS) r_body[it] = ld_stream_u(b.rigid_body_states + (base * HB + q) * 13);
+        }
         load_chunks<ACT4>(b.actions + base * HD, r_act, lane);
     }
 
@@ -93,15 +100,12 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
             }
         }
 #pragma unroll
-        for (int it = 0; it < (BODY4 + WAVE - 1) / WAVE; ++it) {
-            const int k = lane + it * WAVE;
-            if ((it + 1) * WAVE <= BODY4 || k < BODY4) {
-                const float x[4] = {r_body[it].x, r_body[it].y, r_body[it].z, r_body[it].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int f = 4 * k + i, env = f / BODY_ROW, w = f - env * BODY_ROW, body = w / 13, c = w - body * 13;
-                    if (c < 3) s_tile[env * HO + C_BODY + body * 3 + c] = x[i];
-                }
+        for (int it = 0; it < BODY_IT; ++it) {
+            const int q = lane + it * WAVE;
+            if (q < BODY_ROWS) {
+                const int env = q / HB, body = q - env * HB;
+                float *c = s_tile + env * HO + C_BODY + body * 3;
+                c[0] = r_body[it].x; c[1] = r_body[it].y; c[2] = r_body[it].z;
             }
         }
 #pragma unroll
@@ -246,7 +250,8 @@ extern "C" int igx_humanoid_imitate_step(const igx_humanoid_imitate_params *p, c
         return fail(IGX_E_NULL, "%s: a required buffer is NULL", who);
     if (!aligned16(b->root_states) || !aligned16(b->dof_state) || !aligned16(b->rigid_body_states) || !aligned16(b->actions))
         return fail(IGX_E_ALIGN, "%s: input tensors must be 16-byte aligned", who);
-    hipLaunchKernelGGL(humanoid_imitate_kernel, dim3((unsigned)((n + HT - 1) / HT)), dim3(WAVE), 0,
+    static const int reserve = tuning_int("IGX_HIM_LDS_RESERVE", 0);  // unused LDS: caps the waves per CU
+    hipLaunchKernelGGL(humanoid_imitate_kernel, dim3((unsigned)((n + HT - 1) / HT)), dim3(WAVE), (size_t)reserve,
                        static_cast<hipStream_t>(stream), *p, *b, n);
     return launch_status(who);
 }
