@@ -187,3 +187,46 @@ def test_cartpole_reset_idx_vs_oracle(with_rand):
     for k in ("dof_state", "progress", "reset"):
         assert np.array_equal(t[k].cpu().numpy().view(np.uint8), ref[k].view(np.uint8)), k
     ops.cartpole_reset(p, t, _to_dev(np.zeros(0, np.int64)))  # empty list is a no-op
+
+
+@pytest.mark.parametrize("spec_name", ["ant", "humanoid"])
+def test_non_finite_inputs_stay_local(spec_name):
+    """NaN / inf in the simulator's tensors must neither trap nor leak into other environments:
+    the clean environments keep the bits of a run without the poison, and the poisoned ones get
+    the flags the reference's comparisons give (every comparison with NaN is false)."""
+    spec = synthetic.ANT if spec_name == "ant" else synthetic.HUMANOID
+    step, ostep = (ops.ant_step, oracle.ant_step) if spec_name == "ant" else (ops.humanoid_step, oracle.humanoid_step)
+    n = 64 * 7 + 5
+    p = synthetic.loco_params(spec, seed=5, rng_offset=2)
+    clean = synthetic.loco_state(spec, n, 3, DEV, True)
+    if spec_name == "ant":
+        clean["true_objective"] = torch.zeros(n, device=DEV)
+    dirty = {k: v.clone() for k, v in clean.items()}
+    bad = torch.tensor([0, 1, 2, 3, 64, 65, 130, 191, n - 1], device=DEV)
+    dirty["root_states"][bad[0], 2] = float("nan")       # height: z < termination is false
+    dirty["root_states"][bad[1], 3:7] = float("nan")      # orientation
+    dirty["root_states"][bad[2], 0] = float("inf")
+    dirty["root_states"][bad[3], 7:13] = float("-inf")
+    dirty["dof_state"][bad[4]] = float("nan")
+    dirty["sensors"][bad[5]] = float("inf")
+    dirty["actions"][bad[6]] = float("nan")
+    dirty["potentials"][bad[7]] = float("nan")
+    dirty["root_states"][bad[8]] = float("nan")
+    ref = {k: v.cpu().numpy().copy() for k, v in dirty.items()}
+    step(p, clean, n)
+    step(p, dirty, n)
+    torch.cuda.synchronize()
+    ostep(p, ref, n)
+    ok = torch.ones(n, dtype=torch.bool, device=DEV)
+    ok[bad] = False
+    for k in ("obs", "rew", "reset", "progress", "potentials", "prev_potentials", "up_vec", "heading_vec", "dof_state"):
+        assert torch.equal(dirty[k][ok].view(torch.uint8), clean[k][ok].view(torch.uint8)), k
+    for k in ("reset", "progress", "randomize"):
+        assert np.array_equal(dirty[k].cpu().numpy(), ref[k]), k
+    # the poisoned rows agree with the CPU checker wherever it is finite, and are non-finite where it is not
+    got, want = dirty["obs"].cpu().numpy(), ref["obs"]
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    nonangle = [c for c in range(spec["num_obs"]) if c not in H.LOCO_ANGLE_COLS]
+    assert np.array_equal(got[:, nonangle][fin[:, nonangle]].view(np.uint32), want[:, nonangle][fin[:, nonangle]].view(np.uint32))
+    assert np.array_equal(np.isnan(dirty["rew"].cpu().numpy()), np.isnan(ref["rew"]))
