@@ -132,7 +132,7 @@ def test_amp_task_golden(motion):
 
 @pytest.mark.parametrize("n,K,lro,early", [(0, 2, False, True), (1, 2, False, True), (67, 3, True, True),
                                            (1000, 2, False, False), (100003, 4, True, True),
-                                           (1 << 18, 2, False, True)])
+                                           (1 << 20, 2, False, True)])
 def test_amp_step_vs_oracle(n, K, lro, early):
     p = synthetic.amp_params(K, lro, early)
     t = synthetic.amp_state(n, 5, DEV, K)

@@ -138,7 +138,7 @@ def test_ant_vs_oracle(n, with_rand):
     _vs_oracle(synthetic.ANT, ops.ant_step, oracle.ant_step, n, with_rand)
 
 
-@pytest.mark.parametrize("n,with_rand", [(1, True), (129, False), (50001, True), (1 << 19, False)])
+@pytest.mark.parametrize("n,with_rand", [(1, True), (129, False), (50001, True), (1 << 20, False)])
 def test_humanoid_vs_oracle(n, with_rand):
     _vs_oracle(synthetic.HUMANOID, ops.humanoid_step, oracle.humanoid_step, n, with_rand)
 
