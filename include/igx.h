@@ -619,19 +619,22 @@ int igx_clamp(const float *x, float lo, float hi, float *out, int64_t count, igx
  * environment at every step with obs.clone().cpu() and an O(T^2) torch.cat.
  * Here a capture is a gather kernel on the producer's stream into a device
  * staging slot, and a hipMemcpyAsync into pinned host memory on the recorder's
- * own side stream, ordered by events; the producer never waits for the host.
+ * own side stream, ordered by events.  A slot batches consecutive steps up to about
+ * 1 MiB per copy; the producer waits only when the ring of slots is full, i.e. when
+ * it produces faster than the host link drains.
  * Host layout: [max_steps][num_cols][n_rows] fp32 (step-major), pinned.
  * ---------------------------------------------------------------------- */
 typedef struct igx_recorder igx_recorder;
 
-/* Allocates the staging ring (ring_slots x num_cols x n_rows floats on the current
- * device) and the pinned host buffer.  cols: column indices into a row of row_width. */
+/* Allocates the staging ring (ring_slots slots of 1..64 steps of num_cols x n_rows floats on the
+ * current device) and the pinned host buffer.  cols: column indices into a row of row_width. */
 int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t row_width, const int32_t *cols,
                         int32_t num_cols, int32_t ring_slots, int64_t max_steps);
 /* Capture src [n_rows,row_width] (device) as the next step; asynchronous.
  * IGX_E_SIZE once max_steps captures have been taken. */
 int igx_recorder_capture(igx_recorder *r, const float *src, igx_stream_t producer_stream);
-/* Block the host until every capture so far has landed in host memory. */
+/* Block the host until every capture so far has landed in host memory (a partly filled batch is
+ * copied now, ordered behind the stream of the last capture). */
 int igx_recorder_sync(igx_recorder *r);
 int64_t igx_recorder_steps(const igx_recorder *r);
 const float *igx_recorder_host_data(const igx_recorder *r);

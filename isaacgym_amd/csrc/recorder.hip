@@ -1,14 +1,17 @@
 // Trajectory recorder: selected columns of a [n_rows, row_width] device buffer,
 // every step, to pinned host memory without stalling the producer.
 //
-//   capture k:  producer stream   wait(slot_free[k % S])            (only when the ring wraps)
-//                                 gather kernel -> staging slot k % S   [num_cols][n_rows]
-//                                 record(slot_full[k % S])
-//               copy stream       wait(slot_full[k % S])
-//                                 hipMemcpyAsync(host + k * slab, slot, D2H)   (pinned, one contiguous slab)
-//                                 record(slot_free[k % S])
+//   capture k:  producer stream   wait(slot_free[s])                 (first capture of a reused slot s)
+//                                 gather kernel -> step k % B of staging slot s = (k / B) % S
+//                                 record(slot_full[s])               (last capture of the slot's batch)
+//               copy stream       wait(slot_full[s])
+//                                 hipMemcpyAsync(host + first * slab, slot, B slabs, D2H)   (pinned, contiguous)
+//                                 record(slot_free[s])
 //
-// The producer only ever waits for a copy that is S captures old.  Replaces the
+// A slot batches B consecutive steps (B slabs of [num_cols][n_rows] are contiguous on the host
+// as well), B chosen so that a copy moves about 1 MiB: small captures would otherwise be bound
+// by the per-copy latency of the copy engine, and the producer with them.  The producer only
+// ever waits for a copy that is S batches old; igx_recorder_sync flushes a partly filled batch.  Replaces the
 // per-step obs.clone().cpu() + torch.cat of tasks/cartpole_sample.py:119-121,
 // :289-293 (reference paths relative to IsaacGymEnvs/isaacgymenvs/).
 #include <new>
@@ -20,10 +23,13 @@
 
 struct igx_recorder {
     int64_t n_rows = 0, max_steps = 0, steps = 0;
+    int64_t flushed = 0;       // steps whose copy to the host has been enqueued
+    int64_t batch = 1;         // steps per staging slot
+    hipStream_t last_producer = nullptr;
     int32_t row_width = 0, num_cols = 0, ring_slots = 0;
     int device = -1;
     int32_t *d_cols = nullptr;
-    float *d_ring = nullptr;   // [ring_slots][num_cols][n_rows]
+    float *d_ring = nullptr;   // [ring_slots][batch][num_cols][n_rows]
     float *h_data = nullptr;   // [max_steps][num_cols][n_rows], pinned
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> slot_full, slot_free;
@@ -79,10 +85,13 @@ extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t r
     if (!r) return fail(IGX_E_SIZE, "igx_recorder_create: out of host memory");
     r->n_rows = n_rows; r->row_width = row_width; r->num_cols = num_cols; r->ring_slots = ring_slots;
     r->max_steps = max_steps;
+    const int64_t slab_bytes = (int64_t)sizeof(float) * slab;
+    r->batch = ((int64_t)1 << 20) / slab_bytes;
+    r->batch = r->batch < 1 ? 1 : r->batch > 64 ? 64 : r->batch;
     REC_HIP(hipGetDevice(&r->device), "hipGetDevice");
     REC_HIP(hipMalloc(&r->d_cols, sizeof(int32_t) * num_cols), "hipMalloc(cols)");
     REC_HIP(hipMemcpy(r->d_cols, cols, sizeof(int32_t) * num_cols, hipMemcpyHostToDevice), "hipMemcpy(cols)");
-    REC_HIP(hipMalloc(&r->d_ring, sizeof(float) * slab * ring_slots), "hipMalloc(ring)");
+    REC_HIP(hipMalloc(&r->d_ring, sizeof(float) * slab * r->batch * ring_slots), "hipMalloc(ring)");
     REC_HIP(hipHostMalloc(&r->h_data, sizeof(float) * slab * max_steps, hipHostMallocDefault), "hipHostMalloc");
     REC_HIP(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
     for (int s = 0; s < ring_slots; ++s) {
@@ -103,31 +112,49 @@ extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t r
         if (e_ != hipSuccess) return hip_fail(e_, what); \
     } while (0)
 
+// enqueue the copy of steps [flushed, steps) - all in one staging slot - behind the producer's work so far
+static int recorder_flush(igx_recorder *r, hipStream_t ps)
+{
+    if (r->flushed == r->steps) return IGX_OK;
+    const int64_t slab = (int64_t)r->num_cols * r->n_rows;
+    const int slot = (int)((r->flushed / r->batch) % r->ring_slots);
+    const float *stage = r->d_ring + slab * (slot * r->batch + r->flushed % r->batch);
+    const int64_t count = r->steps - r->flushed;
+    REC_HIP(hipEventRecord(r->slot_full[slot], ps), "record(slot_full)");
+    REC_HIP(hipStreamWaitEvent(r->copy_stream, r->slot_full[slot], 0), "wait(slot_full)");
+    REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * slab * count, hipMemcpyDeviceToHost,
+                           r->copy_stream),
+            "hipMemcpyAsync");
+    REC_HIP(hipEventRecord(r->slot_free[slot], r->copy_stream), "record(slot_free)");
+    r->flushed = r->steps;
+    return IGX_OK;
+}
+
 extern "C" int igx_recorder_capture(igx_recorder *r, const float *src, igx_stream_t producer_stream)
 {
     if (!r || !src) return fail(IGX_E_NULL, "igx_recorder_capture: NULL argument");
     if (r->steps >= r->max_steps) return fail(IGX_E_SIZE, "igx_recorder_capture: all %lld steps taken", (long long)r->max_steps);
     hipStream_t ps = static_cast<hipStream_t>(producer_stream);
-    const int slot = (int)(r->steps % r->ring_slots);
+    const int64_t batch_index = r->steps / r->batch, pos = r->steps % r->batch;
+    const int slot = (int)(batch_index % r->ring_slots);
     const int64_t slab = (int64_t)r->num_cols * r->n_rows;
-    float *stage = r->d_ring + slab * slot;
-    if (r->steps >= r->ring_slots) REC_HIP(hipStreamWaitEvent(ps, r->slot_free[slot], 0), "wait(slot_free)");
+    float *stage = r->d_ring + slab * (slot * r->batch + pos);
+    if (pos == 0 && batch_index >= r->ring_slots) REC_HIP(hipStreamWaitEvent(ps, r->slot_free[slot], 0), "wait(slot_free)");
     hipLaunchKernelGGL(recorder_gather_kernel, dim3((unsigned)((r->n_rows + 255) / 256)), dim3(256), 0, ps, src,
                        (int)r->row_width, r->d_cols, (int)r->num_cols, r->n_rows, stage);
     int rc = launch_status("igx_recorder_capture");
     if (rc != IGX_OK) return rc;
-    REC_HIP(hipEventRecord(r->slot_full[slot], ps), "record(slot_full)");
-    REC_HIP(hipStreamWaitEvent(r->copy_stream, r->slot_full[slot], 0), "wait(slot_full)");
-    REC_HIP(hipMemcpyAsync(r->h_data + slab * r->steps, stage, sizeof(float) * slab, hipMemcpyDeviceToHost, r->copy_stream),
-            "hipMemcpyAsync");
-    REC_HIP(hipEventRecord(r->slot_free[slot], r->copy_stream), "record(slot_free)");
     r->steps += 1;
+    r->last_producer = ps;
+    if (pos == r->batch - 1) return recorder_flush(r, ps);
     return IGX_OK;
 }
 
 extern "C" int igx_recorder_sync(igx_recorder *r)
 {
     if (!r) return fail(IGX_E_NULL, "igx_recorder_sync: NULL recorder");
+    int rc = recorder_flush(r, r->last_producer);  // a partly filled batch
+    if (rc != IGX_OK) return rc;
     REC_HIP(hipStreamSynchronize(r->copy_stream), "hipStreamSynchronize");
     return IGX_OK;
 }

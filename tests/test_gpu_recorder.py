@@ -76,3 +76,29 @@ def test_cartpole_sample_sequence_equals_reference(tmp_path):
     assert sorted(back) == ["theta", "x"] and back["x"].shape == (N, T + 1)
     assert torch.equal(back["theta"], seq["theta"])
     assert task.sequence_path.endswith("seq_CartpoleSample-42-%d-%d.pt" % (N, T))
+
+
+@pytest.mark.parametrize("n,ring", [(50, 2), (3000, 1), (200000, 3)])
+def test_recorder_batches_partial_flushes_and_ring_wrap(n, ring):
+    """Small captures are batched into one host copy per staging slot; a sync in the middle of a
+    batch flushes the part taken so far, later captures continue in the same slot, and the ring
+    wraps several times.  Every step must land in its own place on the host."""
+    width, steps = 3, 333
+    rec = TrajectoryRecorder(n, width, dict(x=0, z=2), steps, DEV, ring_slots=ring)
+    want_x, want_z = [], []
+    buf = torch.empty(n, width, device=DEV)
+    for t in range(steps):
+        buf.copy_(torch.full((n, width), float(t), device=DEV) + torch.arange(width, device=DEV) * 0.25)
+        buf[:, 0] += torch.arange(n, device=DEV) * 1e-3
+        rec.capture(buf)
+        want_x.append(buf[:, 0].cpu())
+        want_z.append(buf[:, 2].cpu())
+        if t in (0, 4, 70, 71, 200):   # syncs at arbitrary positions inside a batch
+            part = rec.finish()
+            assert part["x"].shape == (n, t + 1)
+            assert torch.equal(part["x"][:, t], want_x[t]) and torch.equal(part["z"][:, 0], want_z[0])
+    got = rec.finish()
+    assert torch.equal(got["x"], torch.stack(want_x, 1)) and torch.equal(got["z"], torch.stack(want_z, 1))
+    with pytest.raises(IgxError):
+        rec.capture(buf)   # max_steps taken
+    rec.close()

@@ -137,6 +137,42 @@ def main():
         # obs read + corr read + noised obs written back + clamped copy written = 16 B per element, + 17 B flags
         report("tail_ant_noise", timed(lambda i: ops.vec_task_tail(obs[i % 4], out, 5.0, prog, rst, to, 1000, noise=ospec[i % 2],
                                                                    obs_noised=obs[i % 4]), a.steps), 60 * 16 + 17)
+    if on("recorder"):
+        # the fork's sampling mode: two observation columns of every env per step, device -> pinned host
+        import time
+        from isaacgym_amd import _lib
+        from isaacgym_amd.recorder import TrajectoryRecorder
+
+        def run_recorder(nr, steps_r):
+            p = synthetic.cartpole_params(1, 0)
+            sets = [synthetic.cartpole_state(nr, s, DEV) for s in range(4)]
+            plain = timed(lambda i: ops.cartpole_step(p, sets[i % 4], nr), steps_r)
+            rec = TrajectoryRecorder(nr, 4, {"x": 0, "theta": 2}, steps_r + 16, DEV)
+            for i in range(8):   # first touches of the pinned buffer and the ring
+                rec.capture(sets[i % 4]["obs"])
+            _lib.check(_lib.lib().igx_recorder_sync(rec._h))
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for i in range(steps_r):
+                ops.cartpole_step(p, sets[i % 4], nr)
+                rec.capture(sets[i % 4]["obs"])
+            e1.record()
+            e1.synchronize()
+            _lib.check(_lib.lib().igx_recorder_sync(rec._h))
+            wall = time.perf_counter() - t0
+            nbytes = steps_r * 2 * nr * 4
+            r = {"envs": nr, "steps": steps_r, "cartpole_step_us": round(plain, 2),
+                 "step_plus_capture_us_on_producer_stream": round(e0.elapsed_time(e1) / steps_r * 1e3, 2),
+                 "bytes_per_step": 2 * nr * 4, "wall_s_until_all_on_host": round(wall, 5),
+                 "host_landing_GBps": round(nbytes / wall / 1e9, 2)}
+            rec.close()
+            return r
+        res["recorder_small"] = run_recorder(4096, 500)
+        print("recorder_small", json.dumps(res["recorder_small"]), flush=True)
+        res["recorder_large"] = run_recorder(n, 200)
+        print("recorder_large", json.dumps(res["recorder_large"]), flush=True)
     if on("motion"):
         sys.path.insert(0, ".")
         from tests import helpers as H
