@@ -28,13 +28,15 @@ class _Struct(C.Structure):
             self.set(k, v)
 
     def set(self, k, v):
+        if isinstance(v, (int, float)):      # the common case, straight into ctypes
+            setattr(self, k, v)
+            return
         cur = getattr(self, k)
         if isinstance(cur, C.Array):
-            v = list(v)
+            v = v.tolist() if hasattr(v, "tolist") else list(v)
             if len(v) > len(cur):
                 raise ValueError("%s: %d values for %d slots" % (k, len(v), len(cur)))
-            for i, x in enumerate(v):
-                cur[i] = x
+            cur[0:len(v)] = v
         else:
             setattr(self, k, v)
 

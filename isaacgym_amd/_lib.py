@@ -108,7 +108,14 @@ def check(rc):
         raise IgxError(rc, lib().igx_last_error_string().decode("utf-8", "replace"))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream(device):
+    """torch's current stream on `device` as the raw hipStream_t the C ABI takes."""
+    if _raw_stream is not None:
+        index = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return C.c_void_p(_raw_stream(torch.cuda.current_device() if index is None else index))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Wall time of a whole VecTask.step (host code + launches) next to the device time of its kernels.
+Usage: PYTHONPATH=. python tools/step_overhead.py"""
+import time
+
+import torch
+
+from isaacgym_amd import tasks
+
+DEV = "cuda:0"
+for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 8), ("Humanoid", 4096, 21),
+                      ("AllegroHand", 4096, 16), ("ShadowHand", 4096, 20)):
+    t = tasks.make(name, n, DEV)
+    a = torch.zeros(n, acts, device=DEV)
+    for _ in range(20):
+        t.step(a)
+    torch.cuda.synchronize()
+    k = 300
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(k):
+        t.step(a)
+    e1.record()
+    host = (time.perf_counter() - t0) / k * 1e6
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / k * 1e6
+    print("%-12s n=%8d  host %.1f us/step  wall %.1f us/step  device span %.1f us/step" %
+          (name, n, host, wall, e0.elapsed_time(e1) / k * 1e3), flush=True)
