@@ -111,6 +111,8 @@ typedef struct igx_loco_params {
     float dof_limits_upper[IGX_MAX_DOF];
     float motor_efforts[IGX_MAX_DOF]; /* Humanoid only */
     float max_motor_effort;           /* Humanoid only */
+    float clip_obs;                   /* env.clipObservations (+inf copies); read only with obs_clamped */
+    int32_t reserved;
     uint64_t seed;
     uint64_t rng_offset;
 } igx_loco_params;
@@ -134,6 +136,10 @@ typedef struct igx_loco_buffers {
     int64_t *progress;                /* [N] in/out */
     int64_t *randomize;               /* [N] in/out, += 1; may be NULL */
     float *true_objective;            /* [N] out (Ant extras['true_objective']); may be NULL */
+    /* The tail of VecTask.step (tasks/base/vec_task.py:404, :412) folded into the same launch - both
+     * optional, and not for the imitation variants, whose finishing kernel still changes the flags: */
+    float *obs_clamped;               /* [N,num_obs] clamp(obs, -clip_obs, clip_obs), what step() returns; may be NULL */
+    uint8_t *time_outs;               /* [N] bool (progress >= max_episode_length - 1) & (reset != 0) after the step; may be NULL */
 } igx_loco_buffers;
 
 /* Ant.reset_idx (tasks/ant.py:339-366) / Humanoid.reset_idx (tasks/humanoid.py:360-390)

@@ -66,7 +66,7 @@ class LocoParams(_Struct):
                 ("dof_limits_lower", f32 * IGX_MAX_DOF),
                 ("dof_limits_upper", f32 * IGX_MAX_DOF),
                 ("motor_efforts", f32 * IGX_MAX_DOF),
-                ("max_motor_effort", f32),
+                ("max_motor_effort", f32), ("clip_obs", f32), ("reserved", i32),
                 ("seed", u64), ("rng_offset", u64)]
 
 
@@ -77,7 +77,7 @@ class LocoBuffers(_Struct):
                 ("obs", ptr), ("potentials", ptr), ("prev_potentials", ptr),
                 ("up_vec", ptr), ("heading_vec", ptr), ("rew", ptr),
                 ("reset", ptr), ("progress", ptr), ("randomize", ptr),
-                ("true_objective", ptr)]
+                ("true_objective", ptr), ("obs_clamped", ptr), ("time_outs", ptr)]
 
 IGX_ALLEGRO_DOF = 16
 IGX_ALLEGRO_RAND_PER_ENV = 45

@@ -137,6 +137,7 @@ def tensor_ptr(t, dtype=None):
 _I64_FIELDS = {"reset", "progress", "randomize", "reset_goal", "terminate", "motion_ids", "frame_idx0",
                "frame_idx1", "object_indices", "goal_object_indices", "env_ids", "done"}
 _RAW_FIELDS = {"workspace"}  # opaque device scratch: any dtype
+_BOOL_FIELDS = {"time_outs"}
 _F64_FIELDS = {"motion_times", "motion_frame"}
 
 
@@ -144,7 +145,8 @@ def _ptr_checked(name):
     def f(t):
         if name in _RAW_FIELDS:
             return tensor_ptr(t)
-        want = torch.int64 if name in _I64_FIELDS else torch.float64 if name in _F64_FIELDS else torch.float32
+        want = (torch.int64 if name in _I64_FIELDS else torch.float64 if name in _F64_FIELDS else
+                torch.bool if name in _BOOL_FIELDS else torch.float32)
         return tensor_ptr(t, want)
     return f
 

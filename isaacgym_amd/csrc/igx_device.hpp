@@ -201,6 +201,13 @@ __device__ __forceinline__ f4 calc_heading_quat_inv(f4 q)
     return quat_from_angle_axis(-calc_heading(q), f3{0.0f, 0.0f, 1.0f});
 }
 
+// torch.clamp(x, lo, hi): NaN stays NaN (lo <= hi)
+__device__ __forceinline__ float clamp1(float x, float lo, float hi)
+{
+    x = x < lo ? lo : x;
+    return x > hi ? hi : x;
+}
+
 // Philox4x32-10 counter-based generator (Salmon et al., SC'11).  Used for the
 // reset draws when the caller supplies no pre-drawn uniforms.  Counter layout:
 // (env lo, env hi, offset lo, offset hi[23:0] << 8 | block), key = seed.

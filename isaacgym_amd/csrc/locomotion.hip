@@ -217,6 +217,7 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
     st_stream(b.reset + e, rst);
     st_stream(b.progress + e, prog);
     if (b.true_objective) st_stream(b.true_objective + e, lin.x);
+    if (!IMIT && b.time_outs) b.time_outs[e] = ((float)prog >= p.max_episode_length_m1 && rst != 0) ? 1 : 0;
 }
 
 // Everything a tile reads, as it sits in registers after the load phase.
@@ -355,6 +356,24 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
         } else {
             for (int i = lane; i < nvalid * NOBS; i += WAVE) b.obs[base * NOBS + i] = s_tile[i];
         }
+        if (!IMIT && b.obs_clamped) {  // the copy VecTask.step hands to the learner
+            const float hi = p.clip_obs, lo = -p.clip_obs;
+            if (full && dev_aligned16(b.obs_clamped)) {
+                constexpr int N4 = TILE * NOBS / 4;
+                v4f *o4 = reinterpret_cast<v4f *>(b.obs_clamped + base * NOBS);
+#pragma unroll
+                for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
+                    const int k = lane + it * WAVE;
+                    if ((it + 1) * WAVE <= N4 || k < N4) {
+                        v4f v = *reinterpret_cast<const v4f *>(s_tile + 4 * k);
+                        v.x = clamp1(v.x, lo, hi); v.y = clamp1(v.y, lo, hi); v.z = clamp1(v.z, lo, hi); v.w = clamp1(v.w, lo, hi);
+                        st_stream(o4 + k, v);
+                    }
+                }
+            } else {
+                for (int i = lane; i < nvalid * NOBS; i += WAVE) b.obs_clamped[base * NOBS + i] = clamp1(s_tile[i], lo, hi);
+            }
+        }
         wave_sync();
         // up / heading vectors: transpose through the tile's first 384 floats
         constexpr int V3 = 3 * TILE;  // floats per vector array of a tile
@@ -460,6 +479,10 @@ static int check_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64
         if (!b->dof_force) return fail(IGX_E_NULL, "%s: dof_force is NULL", who);
         if (!aligned16(b->dof_force)) return fail(IGX_E_ALIGN, "%s: dof_force must be 16-byte aligned", who);
         if (!(p->max_motor_effort > 0.0f)) return fail(IGX_E_PARAM, "%s: max_motor_effort must be > 0", who);
+    }
+    if (b->obs_clamped) {
+        if (!(p->clip_obs >= 0.0f)) return fail(IGX_E_PARAM, "%s: clip_obs must be >= 0 when obs_clamped is given", who);
+        if (b->obs_clamped == b->obs) return fail(IGX_E_PARAM, "%s: obs_clamped must not alias obs", who);
     }
     return IGX_OK;
 }

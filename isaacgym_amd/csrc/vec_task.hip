@@ -18,13 +18,6 @@
 
 namespace igx {
 
-// torch.clamp(x, lo, hi): NaN stays NaN, lo wins over hi never matters (lo <= hi)
-__device__ __forceinline__ float clamp1(float x, float lo, float hi)
-{
-    x = x < lo ? lo : x;
-    return x > hi ? hi : x;
-}
-
 // Four consecutive floats starting at the multiple of four i0; lanes past `count` read as 0.
 __device__ __forceinline__ void load4(const float *__restrict__ p, int64_t i0, int64_t count, bool vec, float (&v)[4])
 {

@@ -69,6 +69,7 @@ class VecTask:
         # {"actions": [fresh per step, ...], "actions_corr": [corr per re-randomisation, ...], "observations": ...}
         self.replay_noise = None
         self._stage = None
+        self._tail_done = False   # set by a post_physics_step whose kernel already wrote obs_out / time_outs
 
         self.sim = sim
         if sim.num_envs != self.num_environments:
@@ -233,15 +234,17 @@ class VecTask:
         for _ in range(self.control_freq_inv):
             self.sim.simulate()
 
+        self._tail_done = False
         self.post_physics_step()
         self.control_steps += 1
 
-        stage = self._noise_stage("observations", self.obs_buf)
-        ops.vec_task_tail(self.obs_buf, self._obs_out, self.clip_obs, self.progress_buf, self.reset_buf,
-                          self._time_outs, self.max_episode_length,
-                          self.states_buf if self.num_states > 0 else None,
-                          self._states_out if self.num_states > 0 else None,
-                          obs_noised=self.obs_buf if stage else None, **stage)
+        if not self._tail_done:
+            stage = self._noise_stage("observations", self.obs_buf)
+            ops.vec_task_tail(self.obs_buf, self._obs_out, self.clip_obs, self.progress_buf, self.reset_buf,
+                              self._time_outs, self.max_episode_length,
+                              self.states_buf if self.num_states > 0 else None,
+                              self._states_out if self.num_states > 0 else None,
+                              obs_noised=self.obs_buf if stage else None, **stage)
         self.timeout_buf = self._time_outs
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.obs_dict["obs"] = self._obs_out.to(self.rl_device)
@@ -251,6 +254,11 @@ class VecTask:
 
     def zero_actions(self):
         return torch.zeros([self.num_envs, self.num_actions], dtype=torch.float32, device=self.rl_device)
+
+    def _can_fuse_tail(self):
+        """The step kernel may write the clamped observation copy and the time-out flags itself when
+        nothing sits between it and the tail: no observation noise, no privileged states."""
+        return self.num_states == 0 and not self.dr_randomizations.get("observations", None)
 
     def _publish_obs(self):
         ops.clamp(self.obs_buf, -self.clip_obs, self.clip_obs, self._obs_out)

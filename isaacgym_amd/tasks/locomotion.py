@@ -126,7 +126,12 @@ class LocomotionTask(VecTask):
         # ant.py:341-342, humanoid.py:362-363: reset_idx re-randomises, i.e. on steps where some env is reset
         if self.randomize and bool(self.reset_buf.any()):
             self.apply_randomizations(self.randomization_params)
-        self._step_kernel(self._params(), self._buffers(), self.num_envs)
+        p, b = self._params(), self._buffers()
+        if self._can_fuse_tail():  # the clamped copy and the time-out flags of VecTask.step in the same launch
+            p.clip_obs = float(self.clip_obs)
+            b["obs_clamped"], b["time_outs"] = self._obs_out, self._time_outs
+            self._tail_done = True
+        self._step_kernel(p, b, self.num_envs)
         if not self.HUMANOID:
             self.extras["true_objective"] = self._true_objective  # ant.py:332-337
 

@@ -473,6 +473,15 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
         b->reset[e] = rst;
         b->progress[e] = prog;
         if (b->true_objective) b->true_objective[e] = root[7];
+        /* the tail of VecTask.step (tasks/base/vec_task.py:404, :412), not for the imitation variants */
+        if (!im && b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && rst != 0) ? 1 : 0;
+        if (!im && b->obs_clamped) {
+            for (int c = 0; c < NOBS; ++c) { /* torch.clamp: NaN stays NaN */
+                float v = obs[c];
+                v = v < -p->clip_obs ? -p->clip_obs : v;
+                b->obs_clamped[e * NOBS + c] = v > p->clip_obs ? p->clip_obs : v;
+            }
+        }
     }
     return 0;
 }

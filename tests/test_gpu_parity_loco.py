@@ -107,6 +107,10 @@ def _vs_oracle(spec, step, ostep, n, with_rand, steps=2):
     t = synthetic.loco_state(spec, n, 11, DEV, with_rand)
     if not spec["humanoid"]:
         t["true_objective"] = torch.zeros(n, device=DEV)
+    # the tail of VecTask.step folded into the launch: clamped copy (a clip that bites) and time-out flags
+    p.clip_obs = 0.75
+    t["obs_clamped"] = torch.full((n, spec["num_obs"]), 7.0, device=DEV)
+    t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
     ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
     nobs = spec["num_obs"]
     nonangle = [c for c in range(nobs) if c not in H.LOCO_ANGLE_COLS]
@@ -125,6 +129,10 @@ def _vs_oracle(spec, step, ostep, n, with_rand, steps=2):
         H.assert_angle_close(obs[:, ang], ref["obs"][:, ang], what="angles step %d" % s)
         for k in ("dof_state", "potentials", "prev_potentials", "up_vec", "heading_vec", "rew"):
             assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, "%s step %d" % (k, s)
+        assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), "time_outs step %d" % s
+        assert np.array_equal(ref["time_outs"], (ref["progress"] >= spec["max_episode_length"] - 1) & (ref["reset"] != 0))
+        assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -0.75, 0.75)), "obs_clamped step %d" % s
+        assert float(t["obs_clamped"].abs().max()) == 0.75
         # next step: new "physics" state on both sides
         nxt = synthetic.loco_state(spec, n, 100 + s, DEV, with_rand)
         for k in ("root_states", "dof_state", "sensors", "actions") + (("dof_force",) if spec["humanoid"] else ()):
