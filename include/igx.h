@@ -299,6 +299,7 @@ typedef struct igx_allegro_params {
     float dof_speed_scale_dt;     /* dofSpeedScale * dt (relative control) */
     float goal_displacement[3];   /* (-0.2, -0.06, 0.12) */
     float dof_lower[IGX_ALLEGRO_DOF], dof_upper[IGX_ALLEGRO_DOF];
+    float clip_obs;               /* env.clipObservations (+inf copies); read only with obs_clamped / states_clamped */
     uint64_t seed, rng_offset;
 } igx_allegro_params;
 
@@ -327,6 +328,10 @@ typedef struct igx_allegro_buffers {
     float *consecutive_successes;     /* [1] in/out */
     void *workspace;                  /* IGX_ALLEGRO_WORKSPACE_BYTES(n_envs) of device scratch, 16-byte aligned,
                                          contents irrelevant on entry (per-tile partial sums of the reduction) */
+    /* post only, all optional: the tail of VecTask.step (tasks/base/vec_task.py:404, :412-416) in the same launch */
+    float *obs_clamped;               /* [N,num_obs] clamp(obs, -clip_obs, clip_obs) */
+    float *states_clamped;            /* [N,88] clamp(states, ...); needs states */
+    uint8_t *time_outs;               /* [N] bool (progress >= episodeLength - 1) & (reset != 0) after the step */
 } igx_allegro_buffers;
 
 int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
@@ -390,7 +395,7 @@ typedef struct igx_shadow_params {
     float dof_lower[IGX_SHADOW_DOF], dof_upper[IGX_SHADOW_DOF];
     int32_t actuated_dof_indices[IGX_SHADOW_ACTIONS]; /* strictly increasing, in [0, 24) */
     int32_t fingertip_handles[IGX_SHADOW_FINGERTIPS]; /* body indices in [0, num_bodies) */
-    int32_t reserved;
+    float clip_obs;                    /* as in igx_allegro_params */
     uint64_t seed, rng_offset;
 } igx_shadow_params;
 
@@ -416,6 +421,9 @@ typedef struct igx_shadow_buffers {
     float *successes;                 /* [N] in/out */
     float *consecutive_successes;     /* [1] in/out */
     void *workspace;                  /* IGX_ALLEGRO_WORKSPACE_BYTES(n_envs), 16-byte aligned, any contents */
+    float *obs_clamped;               /* as in igx_allegro_buffers */
+    float *states_clamped;            /* [N,211] */
+    uint8_t *time_outs;
 } igx_shadow_buffers;
 
 int igx_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n_envs, igx_stream_t stream);

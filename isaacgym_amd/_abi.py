@@ -100,7 +100,7 @@ class AllegroParams(_Struct):
                 ("dof_speed_scale_dt", f32),
                 ("goal_displacement", f32 * 3),
                 ("dof_lower", f32 * IGX_ALLEGRO_DOF), ("dof_upper", f32 * IGX_ALLEGRO_DOF),
-                ("seed", u64), ("rng_offset", u64)]
+                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64)]
 
 
 class AllegroBuffers(_Struct):
@@ -110,7 +110,8 @@ class AllegroBuffers(_Struct):
                 ("actions", ptr), ("prev_targets", ptr), ("cur_targets", ptr), ("rand", ptr),
                 ("obs", ptr), ("states", ptr), ("rew", ptr),
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
-                ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr)]
+                ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr),
+                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr)]
 
 IGX_SHADOW_DOF, IGX_SHADOW_ACTIONS, IGX_SHADOW_FINGERTIPS, IGX_SHADOW_RAND_PER_ENV = 24, 20, 5, 61
 IGX_SHADOW_OBS = {"openai": 0, "full_no_vel": 1, "full": 2, "full_state": 3}
@@ -133,7 +134,7 @@ class ShadowParams(_Struct):
                 ("goal_displacement", f32 * 3), ("num_bodies", i32),
                 ("dof_lower", f32 * IGX_SHADOW_DOF), ("dof_upper", f32 * IGX_SHADOW_DOF),
                 ("actuated_dof_indices", i32 * IGX_SHADOW_ACTIONS), ("fingertip_handles", i32 * IGX_SHADOW_FINGERTIPS),
-                ("reserved", i32), ("seed", u64), ("rng_offset", u64)]
+                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64)]
 
 
 class ShadowBuffers(_Struct):
@@ -143,7 +144,8 @@ class ShadowBuffers(_Struct):
                 ("actions", ptr), ("prev_targets", ptr), ("cur_targets", ptr), ("rand", ptr),
                 ("obs", ptr), ("states", ptr), ("rew", ptr),
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
-                ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr)]
+                ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr),
+                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr)]
 
 
 IGX_AMP_NUM_BODIES = 15

@@ -259,12 +259,18 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
             st_stream(b.reset_goal + e, fl.rg);
             st_stream(b.progress + e, fl.prog);
             st_stream(b.successes + e, fl.succ);
+            if (b.time_outs) b.time_outs[e] = ((float)fl.prog >= p.max_episode_length_m1 && fl.rst != 0) ? 1 : 0;
         }
     }
     wave_sync();
     drain_rows<NOBS, T>(obs_out + base * NOBS, s_tile, nvalid, lane);
-    if (REWARD && OBS == IGX_ALLEGRO_OBS_FULL_STATE && b.states)  // asymmetric observations: same 88 columns
+    // the clamped copies VecTask.step hands to the learner (this launch writes obs, or only states)
+    float *clamped = REWARD ? b.obs_clamped : b.states_clamped;
+    if (clamped) drain_rows_clamped<NOBS, T>(clamped + base * NOBS, s_tile, nvalid, lane, p.clip_obs);
+    if (REWARD && OBS == IGX_ALLEGRO_OBS_FULL_STATE && b.states) {  // asymmetric observations: same 88 columns
         drain_rows<NOBS, T>(b.states + base * NOBS, s_tile, nvalid, lane);
+        if (b.states_clamped) drain_rows_clamped<NOBS, T>(b.states_clamped + base * NOBS, s_tile, nvalid, lane, p.clip_obs);
+    }
     if (REWARD) store_tile_record(b.workspace, fin, live ? fl.rst : 0, lane);
 }
 
@@ -297,6 +303,12 @@ static int check_allegro(const igx_allegro_params *p, const igx_allegro_buffers 
         REQ(workspace, true);
         if (p->obs_type == IGX_ALLEGRO_OBS_FULL_STATE || b->states) REQ(dof_force, true);
         if (b->states && !aligned16(b->states)) return fail(IGX_E_ALIGN, "%s: states must be 16-byte aligned", who);
+        if (b->obs_clamped || b->states_clamped) {
+            if (!(p->clip_obs >= 0.0f)) return fail(IGX_E_PARAM, "%s: clip_obs must be >= 0 when a clamped copy is asked for", who);
+            if (b->states_clamped && !b->states) return fail(IGX_E_NULL, "%s: states_clamped needs states", who);
+            if (b->obs_clamped == b->obs || (b->states_clamped && b->states_clamped == b->states))
+                return fail(IGX_E_PARAM, "%s: a clamped copy must not alias its source", who);
+        }
     } else {
         REQ(goal_object_indices, false);
         REQ(goal_init_state, false);

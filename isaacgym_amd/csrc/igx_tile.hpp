@@ -187,6 +187,28 @@ __device__ __forceinline__ void drain_rows(float *__restrict__ g, const float *s
     }
 }
 
+// drain_rows with torch.clamp(x, -clip, clip) applied on the way out
+template <int ROWW, int T = WAVE>
+__device__ __forceinline__ void drain_rows_clamped(float *__restrict__ g, const float *s_tile, int nvalid, int lane, float clip)
+{
+    if (nvalid == T && dev_aligned16(g)) {
+        constexpr int N4 = T * ROWW / 4;
+        v4f *o4 = reinterpret_cast<v4f *>(g);
+#pragma unroll
+        for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= N4 || k < N4) {
+                v4f v = *reinterpret_cast<const v4f *>(s_tile + 4 * k);
+                v.x = clamp1(v.x, -clip, clip); v.y = clamp1(v.y, -clip, clip);
+                v.z = clamp1(v.z, -clip, clip); v.w = clamp1(v.w, -clip, clip);
+                st_stream(o4 + k, v);
+            }
+        }
+    } else {
+        for (int i = lane; i < nvalid * ROWW; i += WAVE) g[i] = clamp1(s_tile[i], -clip, clip);
+    }
+}
+
 // Park a tile's ROWW-float rows (chunks already in registers for a full tile,
 // or straight from global memory for a partial one) linearly at s.
 template <int ROWW, int T = WAVE, int ITERS = 1>

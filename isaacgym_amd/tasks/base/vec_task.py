@@ -255,10 +255,19 @@ class VecTask:
     def zero_actions(self):
         return torch.zeros([self.num_envs, self.num_actions], dtype=torch.float32, device=self.rl_device)
 
-    def _can_fuse_tail(self):
+    def _can_fuse_tail(self, states_too=False):
         """The step kernel may write the clamped observation copy and the time-out flags itself when
-        nothing sits between it and the tail: no observation noise, no privileged states."""
-        return self.num_states == 0 and not self.dr_randomizations.get("observations", None)
+        nothing sits between it and the tail: no observation noise, and no privileged states unless
+        the kernel clamps those as well."""
+        return (states_too or self.num_states == 0) and not self.dr_randomizations.get("observations", None)
+
+    def _fuse_tail(self, params, buffers):
+        """Hand the persistent tail outputs to a kernel that fills them (obs_clamped, states_clamped, time_outs)."""
+        params.clip_obs = float(self.clip_obs)
+        buffers["obs_clamped"], buffers["time_outs"] = self._obs_out, self._time_outs
+        if self.num_states > 0:
+            buffers["states_clamped"] = self._states_out
+        self._tail_done = True
 
     def _publish_obs(self):
         ops.clamp(self.obs_buf, -self.clip_obs, self.clip_obs, self._obs_out)

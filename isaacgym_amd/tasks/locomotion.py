@@ -128,9 +128,7 @@ class LocomotionTask(VecTask):
             self.apply_randomizations(self.randomization_params)
         p, b = self._params(), self._buffers()
         if self._can_fuse_tail():  # the clamped copy and the time-out flags of VecTask.step in the same launch
-            p.clip_obs = float(self.clip_obs)
-            b["obs_clamped"], b["time_outs"] = self._obs_out, self._time_outs
-            self._tail_done = True
+            self._fuse_tail(p, b)
         self._step_kernel(p, b, self.num_envs)
         if not self.HUMANOID:
             self.extras["true_objective"] = self._true_objective  # ant.py:332-337

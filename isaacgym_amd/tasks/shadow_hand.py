@@ -170,13 +170,15 @@ class ShadowHand(VecTask):
         self.sim.apply_dof_position_targets(self.cur_targets)
 
     def post_physics_step(self):
+        p, b = self._params(), self._buffers()
+        if self._can_fuse_tail(states_too=True):  # clamped copies and time-out flags of VecTask.step in the same launch
+            self._fuse_tail(p, b)
         if distributed.world_size(self._group) > 1:
-            p, b = self._params(), self._buffers()
             ops.shadow_post_physics_shard(p, b, self.num_envs)
             records = distributed.gather_records(self._workspace.view(torch.uint8)[:16], self._group)
             ops.shadow_finalize_shards(p, b, records)
         else:
-            ops.shadow_post_physics(self._params(), self._buffers(), self.num_envs)
+            ops.shadow_post_physics(p, b, self.num_envs)
         self.extras["consecutive_successes"] = self.consecutive_successes.mean()
         if self.print_success_stat:  # :426-435 (host prints: synchronises, as in the reference)
             self.total_resets = self.total_resets + self.reset_buf.sum()

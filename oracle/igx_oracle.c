@@ -656,6 +656,16 @@ int orc_calc_heading_quat_inv(const float *q, float *o, int64_t n)
     return 0;
 }
 
+/* torch.clamp(row, -clip, clip) of one observation row: NaN stays NaN (tasks/base/vec_task.py:412) */
+static void clamp_row(const float *src, float *dst, int count, float clip)
+{
+    for (int c = 0; c < count; ++c) {
+        float v = src[c];
+        v = v < -clip ? -clip : v;
+        dst[c] = v > clip ? clip : v;
+    }
+}
+
 /* ------------------------------------------------------- AllegroHand --- */
 #define PI_F 3.14159274f /* float32(np.pi) */
 
@@ -803,6 +813,8 @@ static int allegro_post(const igx_allegro_params *p, const igx_allegro_buffers *
         quat_mul(obj + 3, gconj, qd);
         allegro_obs_row(p, b, e, p->obs_type, obj, goal, qd, b->obs + e * nobs);
         if (b->states) allegro_obs_row(p, b, e, IGX_ALLEGRO_OBS_FULL_STATE, obj, goal, qd, b->states + e * 88);
+        if (b->obs_clamped) clamp_row(b->obs + e * nobs, b->obs_clamped + e * nobs, nobs, p->clip_obs);
+        if (b->states && b->states_clamped) clamp_row(b->states + e * 88, b->states_clamped + e * 88, 88, p->clip_obs);
 
         /* compute_hand_reward */
         float dpos[3] = { obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2] };
@@ -838,6 +850,7 @@ static int allegro_post(const igx_allegro_params *p, const igx_allegro_buffers *
         b->reset_goal[e] = goal_resets;
         b->progress[e] = prog;
         b->successes[e] = successes;
+        if (b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && resets != 0) ? 1 : 0;
         num_resets += resets;
         fin += (double)(successes * (float)resets);
     }
@@ -1018,6 +1031,8 @@ static int shadow_post(const igx_shadow_params *p, const igx_shadow_buffers *b, 
         quat_mul(obj + 3, gconj, qd);
         shadow_obs_row(p, b, e, p->obs_type, obj, goal, qd, b->obs + e * nobs);
         if (b->states) shadow_obs_row(p, b, e, IGX_SHADOW_OBS_FULL_STATE, obj, goal, qd, b->states + e * 211);
+        if (b->obs_clamped) clamp_row(b->obs + e * nobs, b->obs_clamped + e * nobs, nobs, p->clip_obs);
+        if (b->states && b->states_clamped) clamp_row(b->states + e * 211, b->states_clamped + e * 211, 211, p->clip_obs);
 
         float dpos[3] = { obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2] };
         float goal_dist = norm3(dpos);
@@ -1051,6 +1066,7 @@ static int shadow_post(const igx_shadow_params *p, const igx_shadow_buffers *b, 
         b->reset_goal[e] = goal_resets;
         b->progress[e] = prog;
         b->successes[e] = successes;
+        if (b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && resets != 0) ? 1 : 0;
         num_resets += resets;
         fin += (double)(successes * (float)resets);
     }

@@ -28,6 +28,11 @@ def test_shadow_golden(variant):
 def test_shadow_vs_oracle(n, obs_type, asym):
     p = synthetic.shadow_params(obs_type, seed=99, rng_offset=3)
     t = synthetic.shadow_state(n, 21, DEV, obs_type, asym)
+    # the tail of VecTask.step folded into the post launch: clamped copies (a clip that bites) and time-out flags
+    p.clip_obs = 0.5
+    t["obs_clamped"] = torch.full_like(t["obs"], 7.0)
+    t["states_clamped"] = torch.full((n, 211), 7.0, device=DEV) if asym else None
+    t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
     ref = {k: (v.cpu().numpy().copy() if v is not None else None) for k, v in t.items()}
     for step in range(2):
         p.rng_offset = 3 + step
@@ -56,6 +61,12 @@ def test_shadow_vs_oracle(n, obs_type, asym):
             H.assert_close(t["states"].cpu().numpy(), ref["states"], what="states step %d" % step)
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew step %d" % step)
         H.assert_close(t["consecutive_successes"].cpu().numpy(), ref["consecutive_successes"], what="cons")
+        assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), "time_outs step %d" % step
+        assert np.array_equal(ref["time_outs"], (ref["progress"] >= 599) & (ref["reset"] != 0))
+        assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -0.5, 0.5)), "obs_clamped step %d" % step
+        assert np.array_equal(ref["obs_clamped"], np.clip(ref["obs"], -0.5, 0.5))
+        if asym:
+            assert torch.equal(t["states_clamped"], torch.clamp(t["states"], -0.5, 0.5)), "states_clamped step %d" % step
 
 
 def test_shadow_two_shards_equal_one_on_device():
