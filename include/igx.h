@@ -505,6 +505,8 @@ typedef struct igx_amp_params {
     int32_t key_body_ids[4];          /* 5, 8, 11, 14 */
     float termination_height;         /* 0.5 */
     float max_episode_length_m1;      /* episodeLength - 1 */
+    float clip_obs;                   /* env.clipObservations (+inf copies); read only with obs_clamped */
+    int32_t reserved;
 } igx_amp_params;
 
 typedef struct igx_amp_buffers {
@@ -516,6 +518,9 @@ typedef struct igx_amp_buffers {
     float *amp_obs;                 /* [N,K,105] newest first */
     float *rew;                     /* [N] */
     int64_t *reset, *terminate, *progress; /* [N] */
+    /* step only, optional: the tail of VecTask.step (tasks/base/vec_task.py:404, :412) in the same launch */
+    float *obs_clamped;             /* [N,105] clamp(obs, -clip_obs, clip_obs) */
+    uint8_t *time_outs;             /* [N] bool (progress >= episodeLength - 1) & (reset != 0) after the step */
 } igx_amp_buffers;
 
 /* HumanoidAMP.post_physics_step (tasks/humanoid_amp.py:125-134 over

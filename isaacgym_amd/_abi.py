@@ -170,13 +170,13 @@ class MotionStateOut(_Struct):
 class AmpParams(_Struct):
     _fields_ = [("num_amp_obs_steps", i32), ("local_root_obs", i32), ("enable_early_termination", i32),
                 ("num_contact_bodies", i32), ("contact_body_ids", i32 * 4), ("key_body_ids", i32 * 4),
-                ("termination_height", f32), ("max_episode_length_m1", f32)]
+                ("termination_height", f32), ("max_episode_length_m1", f32), ("clip_obs", f32), ("reserved", i32)]
 
 
 class AmpBuffers(_Struct):
     _fields_ = [("root_states", ptr), ("dof_state", ptr), ("rigid_body_state", ptr), ("contact_forces", ptr),
                 ("obs", ptr), ("amp_obs", ptr), ("rew", ptr), ("reset", ptr), ("terminate", ptr),
-                ("progress", ptr)]
+                ("progress", ptr), ("obs_clamped", ptr), ("time_outs", ptr)]
 
 
 IGX_NOISE_ADDITIVE, IGX_NOISE_SCALING = 0, 1

@@ -495,6 +495,8 @@ __global__ __launch_bounds__(WAVE) void amp_step_pair_kernel(const igx_amp_param
             st_stream(b.reset + eo, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
             st_stream(b.terminate + eo, terminated);
             st_stream(b.progress + eo, prog);
+            // reset is 1 whenever the episode length is reached, so the time-out flag is that comparison
+            if (b.time_outs) b.time_outs[eo] = ((float)prog >= p.max_episode_length_m1) ? 1 : 0;
         }
     }
     wave_sync();
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(WAVE) void amp_step_pair_kernel(const igx_amp_param
     } else {
         for (int i = lane; i < nvalid * NO; i += WAVE) b.obs[base * NO + i] = s_tile[i];
     }
+    if (b.obs_clamped) drain_rows_clamped<NO, T>(b.obs_clamped + base * NO, s_tile, nvalid, lane, p.clip_obs);
 
     // ---- AMP history
     float *amp = b.amp_obs + base * K * NO;
@@ -589,6 +592,10 @@ static int check_amp(const igx_amp_params *p, const igx_amp_buffers *b, int64_t 
         return fail(IGX_E_NULL, "%s: a required buffer is NULL", who);
     if (!aligned16(b->root_states) || !aligned16(b->dof_state))
         return fail(IGX_E_ALIGN, "%s: root_states / dof_state must be 16-byte aligned", who);
+    if (b->obs_clamped) {
+        if (!(p->clip_obs >= 0.0f)) return fail(IGX_E_PARAM, "%s: clip_obs must be >= 0 when obs_clamped is given", who);
+        if (b->obs_clamped == b->obs) return fail(IGX_E_PARAM, "%s: obs_clamped must not alias obs", who);
+    }
     return IGX_OK;
 }
 

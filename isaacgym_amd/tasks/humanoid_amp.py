@@ -145,7 +145,10 @@ class HumanoidAMPBase(VecTask):
 
     def post_physics_step(self):  # humanoid_amp_base.py:424-438 (+ the AMP history, humanoid_amp.py:312-330)
         self._refresh_sim_tensors()
-        ops.humanoid_amp_step(self._params(), self._buffers(), self.num_envs)
+        p, b = self._params(), self._buffers()
+        if self._can_fuse_tail():  # clamped copy and time-out flags of VecTask.step in the same launch
+            self._fuse_tail(p, b)
+        ops.humanoid_amp_step(p, b, self.num_envs)
         self.extras["terminate"] = self._terminate_buf
 
     def reset_idx(self, env_ids):  # humanoid_amp_base.py:165-169, :392-408

@@ -1283,6 +1283,8 @@ int orc_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int
         b->reset[e] = ((float)prog >= p->max_episode_length_m1) ? 1 : terminated;
         b->terminate[e] = terminated;
         b->progress[e] = prog;
+        if (b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && b->reset[e] != 0) ? 1 : 0;
+        if (b->obs_clamped) clamp_row(b->obs + e * 105, b->obs_clamped + e * 105, 105, p->clip_obs);
         float *a = b->amp_obs + e * K * 105;
         for (int k = K - 2; k >= 0; --k) memcpy(a + (k + 1) * 105, a + k * 105, 105 * sizeof(float));
         memcpy(a, obs, sizeof obs);

@@ -136,6 +136,10 @@ def test_amp_task_golden(motion):
 def test_amp_step_vs_oracle(n, K, lro, early):
     p = synthetic.amp_params(K, lro, early)
     t = synthetic.amp_state(n, 5, DEV, K)
+    # the tail of VecTask.step folded into the launch: clamped copy (a clip that bites) and time-out flags
+    p.clip_obs = 0.4
+    t["obs_clamped"] = torch.full((n, 105), 7.0, device=DEV)
+    t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
     ref = {k: host(v).copy() for k, v in t.items()}
     for step in range(2):
         ops.humanoid_amp_step(p, t, n)
@@ -146,6 +150,10 @@ def test_amp_step_vs_oracle(n, K, lro, early):
         for k in ("reset", "terminate", "progress"):
             assert np.array_equal(host(t[k]), ref[k]), "%s step %d" % (k, step)
         assert np.array_equal(host(t["rew"]), ref["rew"])
+        assert np.array_equal(host(t["time_outs"]), ref["time_outs"]), "time_outs step %d" % step
+        assert np.array_equal(ref["time_outs"], (ref["progress"] >= 299) & (ref["reset"] != 0))
+        assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -0.4, 0.4)), "obs_clamped step %d" % step
+        assert np.array_equal(ref["obs_clamped"], np.clip(ref["obs"], -0.4, 0.4))
         H.assert_close(host(t["obs"]), ref["obs"], scale=np.pi, rtol=2e-5, what="obs step %d" % step)
         got, want = host(t["amp_obs"]), ref["amp_obs"]
         H.assert_close(got[:, 0], want[:, 0], scale=np.pi, rtol=2e-5, what="amp_obs current")
