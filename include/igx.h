@@ -235,7 +235,7 @@ typedef struct igx_humanoid_imitate_params {
     float max_episode_length_m1;
     int32_t reserved;
     float targets[3];
-    float reserved2;
+    float clip_obs;               /* env.clipObservations (+inf copies); read only with obs_clamped */
     float dof_limits_lower[IGX_HIM_DOF + 1];
     float dof_limits_upper[IGX_HIM_DOF + 1];
     uint64_t seed;
@@ -256,6 +256,9 @@ typedef struct igx_humanoid_imitate_buffers {
     float *prev_potentials;            /* [N] " */
     float *rew;                        /* [N] */
     int64_t *reset, *progress, *randomize; /* [N]; randomize may be NULL */
+    /* optional: the tail of VecTask.step (tasks/base/vec_task.py:404, :412) in the same launch */
+    float *obs_clamped;                /* [N,205] clamp(obs, -clip_obs, clip_obs) */
+    uint8_t *time_outs;                /* [N] bool (progress >= episodeLength - 1) & (reset != 0) after the step */
 } igx_humanoid_imitate_buffers;
 
 int igx_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_humanoid_imitate_buffers *b,

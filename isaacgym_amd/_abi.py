@@ -210,7 +210,7 @@ IGX_HIM_DOF, IGX_HIM_BODIES, IGX_HIM_OBS = 63, 22, 205
 class HumanoidImitateParams(_Struct):
     _fields_ = [("dt", f32), ("dof_vel_scale", f32), ("up_weight", f32), ("actions_cost_scale", f32),
                 ("termination_height", f32), ("termination_radius_sq", f32), ("max_episode_length_m1", f32),
-                ("reserved", i32), ("targets", f32 * 3), ("reserved2", f32),
+                ("reserved", i32), ("targets", f32 * 3), ("clip_obs", f32),
                 ("dof_limits_lower", f32 * (IGX_HIM_DOF + 1)), ("dof_limits_upper", f32 * (IGX_HIM_DOF + 1)),
                 ("seed", u64), ("rng_offset", u64)]
 
@@ -219,7 +219,7 @@ class HumanoidImitateBuffers(_Struct):
     _fields_ = [("root_states", ptr), ("dof_state", ptr), ("rigid_body_states", ptr), ("actions", ptr),
                 ("initial_root_states", ptr), ("initial_dof_pos", ptr), ("rand", ptr), ("motion_frame", ptr),
                 ("obs", ptr), ("potentials", ptr), ("prev_potentials", ptr), ("rew", ptr),
-                ("reset", ptr), ("progress", ptr), ("randomize", ptr)]
+                ("reset", ptr), ("progress", ptr), ("randomize", ptr), ("obs_clamped", ptr), ("time_outs", ptr)]
 
 
 class ImitateArgs(_Struct):

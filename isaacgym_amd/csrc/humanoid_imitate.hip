@@ -216,6 +216,7 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
             st_stream(b.reset + e, rst2);
             st_stream(b.progress + e, prog2);
             if (b.randomize) st_stream(b.randomize + e, rnd_e + 1);
+            if (b.time_outs) b.time_outs[e] = ((float)prog2 >= p.max_episode_length_m1 && rst2 != 0) ? 1 : 0;
         }
     }
 
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
     } else {
         for (int i = lane; i < nvalid * HO; i += WAVE) b.obs[base * HO + i] = s_tile[i];
     }
+    if (b.obs_clamped) drain_rows_clamped<HO, HT>(b.obs_clamped + base * HO, s_tile, nvalid, lane, p.clip_obs);
 }
 
 }  // namespace igx
@@ -248,6 +250,8 @@ extern "C" int igx_humanoid_imitate_step(const igx_humanoid_imitate_params *p, c
         !b->initial_dof_pos || !b->motion_frame || !b->obs || !b->potentials || !b->prev_potentials || !b->rew ||
         !b->reset || !b->progress)
         return fail(IGX_E_NULL, "%s: a required buffer is NULL", who);
+    if (b->obs_clamped && (!(p->clip_obs >= 0.0f) || b->obs_clamped == b->obs))
+        return fail(IGX_E_PARAM, "%s: obs_clamped needs clip_obs >= 0 and must not alias obs", who);
     if (!aligned16(b->root_states) || !aligned16(b->dof_state) || !aligned16(b->rigid_body_states) || !aligned16(b->actions))
         return fail(IGX_E_ALIGN, "%s: input tensors must be 16-byte aligned", who);
     static const int reserve = tuning_int("IGX_HIM_LDS_RESERVE", 0);  // unused LDS: caps the waves per CU

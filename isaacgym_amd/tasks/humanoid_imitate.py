@@ -87,7 +87,10 @@ class HumanoidImitate(VecTask):
         self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
-        ops.humanoid_imitate_step(self._params(), self._buffers(), self.num_envs)
+        p, b = self._params(), self._buffers()
+        if self._can_fuse_tail():  # clamped copy and time-out flags of VecTask.step in the same launch
+            self._fuse_tail(p, b)
+        ops.humanoid_imitate_step(p, b, self.num_envs)
 
     def reset_idx(self, env_ids):
         """reset_idx on an id list = the flagged reset of the step kernel: raise the flags; they are

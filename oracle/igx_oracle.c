@@ -1455,6 +1455,8 @@ int orc_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_hu
         b->rew[e] = (float)total;
         b->reset[e] = rst;
         b->progress[e] = prog;
+        if (b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && rst != 0) ? 1 : 0;
+        if (b->obs_clamped) clamp_row(b->obs + e * NO, b->obs_clamped + e * NO, NO, p->clip_obs);
     }
     return 0;
 }

@@ -24,6 +24,10 @@ def test_humanoid_imitate_golden():
 def test_humanoid_imitate_vs_oracle(n, with_rand):
     p = synthetic.him_params(seed=7, rng_offset=3)
     t = synthetic.him_state(n, 5, DEV, with_rand)
+    # the tail of VecTask.step folded into the launch: clamped copy (a clip that bites) and time-out flags
+    p.clip_obs = 0.6
+    t["obs_clamped"] = torch.full((n, 205), 7.0, device=DEV)
+    t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
     ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
     for step in range(2):
         p.rng_offset = 3 + step
@@ -37,6 +41,10 @@ def test_humanoid_imitate_vs_oracle(n, with_rand):
         for k in ("obs", "dof_state", "potentials", "prev_potentials"):
             assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, "%s step %d" % (k, step)
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew step %d" % step)
+        assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), "time_outs step %d" % step
+        assert np.array_equal(ref["time_outs"], (ref["progress"].astype(np.float32) >= p.max_episode_length_m1) & (ref["reset"] != 0))
+        assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -0.6, 0.6)), "obs_clamped step %d" % step
+        assert np.array_equal(ref["obs_clamped"], np.clip(ref["obs"], -0.6, 0.6))
 
 
 def test_humanoid_imitate_class():
