@@ -307,8 +307,8 @@ typedef struct igx_allegro_params {
 } igx_allegro_params;
 
 /* scratch for the cross-environment reduction: 16-byte records - the total, then one per tile of
- * at least 32 environments */
-#define IGX_ALLEGRO_WORKSPACE_BYTES(n_envs) (16 * (((int64_t)(n_envs) + 31) / 32 + 1))
+ * at least 16 environments */
+#define IGX_ALLEGRO_WORKSPACE_BYTES(n_envs) (16 * (((int64_t)(n_envs) + 15) / 16 + 1))
 
 typedef struct igx_allegro_buffers {
     float *dof_state;                 /* [N,16,2] in (post) / in-out (pre: reset envs) */

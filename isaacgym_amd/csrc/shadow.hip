@@ -25,7 +25,7 @@
 namespace igx {
 
 constexpr int SD = IGX_SHADOW_DOF, SA = IGX_SHADOW_ACTIONS, SF = IGX_SHADOW_FINGERTIPS, SS = 6 * IGX_SHADOW_FINGERTIPS;
-constexpr int ST = 32;  // environments per tile in the post kernel
+constexpr int ST = 32;  // environments per tile in the post kernel (16 measured the same)
 
 template <int OBS>
 struct ShadowLayout {

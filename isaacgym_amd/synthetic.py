@@ -143,7 +143,7 @@ def allegro_params(obs_type="full_state", seed=0, rng_offset=0, **over):
 
 def allegro_workspace_floats(n):
     """IGX_ALLEGRO_WORKSPACE_BYTES(n) / 4."""
-    return 4 * ((n + 31) // 32 + 1)
+    return 4 * ((n + 15) // 16 + 1)
 
 
 def allegro_state(n, seed, device, obs_type="full_state", asymmetric=False):

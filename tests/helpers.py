@@ -136,7 +136,7 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
              obs=zeros((N, nobs), np.float32), states=zeros((N, 88), np.float32) if asym else None,
              rew=zeros((N,), np.float32), reset=to_buf(np.ones(N, np.int64)), reset_goal=to_buf(np.ones(N, np.int64)),
              progress=zeros((N,), np.int64), randomize=zeros((N,), np.int64), successes=zeros((N,), np.float32),
-             consecutive_successes=zeros((1,), np.float32), workspace=zeros((4 * ((N + 31) // 32 + 1),), np.float32))
+             consecutive_successes=zeros((1,), np.float32), workspace=zeros((4 * ((N + 15) // 16 + 1),), np.float32))
 
     def put(name, arr):
         dst = b[name]
@@ -230,7 +230,7 @@ def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
              obs=zeros((N, nobs), np.float32), states=zeros((N, 211), np.float32) if asym else None,
              rew=zeros((N,), np.float32), reset=to_buf(np.ones(N, np.int64)), reset_goal=to_buf(np.ones(N, np.int64)),
              progress=zeros((N,), np.int64), randomize=zeros((N,), np.int64), successes=zeros((N,), np.float32),
-             consecutive_successes=zeros((1,), np.float32), workspace=zeros((4 * ((N + 31) // 32 + 1),), np.float32))
+             consecutive_successes=zeros((1,), np.float32), workspace=zeros((4 * ((N + 15) // 16 + 1),), np.float32))
 
     def put(name, arr):
         dst = b[name]
