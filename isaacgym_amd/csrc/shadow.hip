@@ -173,7 +173,6 @@ __global__ __launch_bounds__(WAVE) void shadow_post_kernel(const igx_shadow_para
 {
     using L = ShadowLayout<OBS>;
     constexpr int NOBS = L::NOBS, T = ST;
-    constexpr int FT_IT = (T * SF + WAVE - 1) / WAVE;
     __shared__ __align__(16) float s_tile[T * NOBS];
     __shared__ __align__(16) float s_lim[2 * SD];
     __shared__ int s_ft[SF];
@@ -203,20 +202,23 @@ __global__ __launch_bounds__(WAVE) void shadow_post_kernel(const igx_shadow_para
     }
     RowWindow<T, T * NOBS> object_rows;
     object_rows.load(b.root_state_tensor, b.object_indices, e, live, full, lane, obj);
-    // fingertip bodies: pair q = (environment q / 5, fingertip q % 5)
-    float ft[FT_IT][L::FT_W == 13 ? 13 : 4];
+    // fingertip bodies, row q = (environment q / 5, fingertip q % 5).  Whole 13-float states: four lanes
+    // share a row (four 16-byte pieces, the last one overlapping), so that the lanes of one load instruction
+    // fall into 16 rows instead of 64 - the gather is bound by the number of distinct lines an
+    // instruction touches.  Positions only: one lane per row, one 16-byte load.
+    constexpr int FT_ROWS_PER_IT = L::FT_W == 13 ? WAVE / 4 : WAVE;
+    constexpr int FT_ITERS = (T * SF + FT_ROWS_PER_IT - 1) / FT_ROWS_PER_IT;
+    v4f ft[FT_ITERS];
 #pragma unroll
-    for (int it = 0; it < FT_IT; ++it) {
-        const int q = lane + it * WAVE, env = q / SF, f = q - env * SF;
+    for (int it = 0; it < FT_ITERS; ++it) {
+        const int q = it * FT_ROWS_PER_IT + (L::FT_W == 13 ? lane >> 2 : lane), env = q / SF, f = q - env * SF;
         if (env < nvalid) {
             const float *row = b.rigid_body_states + ((base + env) * p.num_bodies + s_ft[f]) * 13;
-            const v4f a = ld_stream_u(row);
-            ft[it][0] = a.x; ft[it][1] = a.y; ft[it][2] = a.z; ft[it][3] = a.w;
             if constexpr (L::FT_W == 13) {
-                const v4f c = ld_stream_u(row + 4), d = ld_stream_u(row + 8);
-                ft[it][4] = c.x; ft[it][5] = c.y; ft[it][6] = c.z; ft[it][7] = c.w;
-                ft[it][8] = d.x; ft[it][9] = d.y; ft[it][10] = d.z; ft[it][11] = d.w;
-                ft[it][12] = __builtin_nontemporal_load(row + 12);
+                const int part = lane & 3;  // pieces at floats 0, 4, 8 and 9 (the last one overlaps: its .w is float 12)
+                ft[it] = ld_stream_u(row + (part < 3 ? 4 * part : 9));
+            } else {
+                ft[it] = ld_stream_u(row);
             }
         }
     }
@@ -279,12 +281,20 @@ __global__ __launch_bounds__(WAVE) void shadow_post_kernel(const igx_shadow_para
         }
     }
 #pragma unroll
-    for (int it = 0; it < FT_IT; ++it) {
-        const int q = lane + it * WAVE, env = q / SF, f = q - env * SF;
+    for (int it = 0; it < FT_ITERS; ++it) {
+        const int q = it * FT_ROWS_PER_IT + (L::FT_W == 13 ? lane >> 2 : lane), env = q / SF, f = q - env * SF;
         if (env < nvalid) {
             float *c = s_tile + env * NOBS + L::C_FT + f * L::FT_W;
-#pragma unroll
-            for (int i = 0; i < L::FT_W; ++i) c[i] = ft[it][i];
+            if constexpr (L::FT_W == 13) {
+                const int part = lane & 3;
+                if (part < 3) {
+                    c[4 * part] = ft[it].x; c[4 * part + 1] = ft[it].y; c[4 * part + 2] = ft[it].z; c[4 * part + 3] = ft[it].w;
+                } else {
+                    c[12] = ft[it].w;
+                }
+            } else {
+                c[0] = ft[it].x; c[1] = ft[it].y; c[2] = ft[it].z;
+            }
         }
     }
     wave_sync();
