@@ -70,12 +70,16 @@ __device__ __forceinline__ void stage_rows(const v4f (&v)[ITERS], float *s_tile,
                 const int env = k / R4, part = k - env * R4;
                 *reinterpret_cast<v4f *>(s_tile + env * NOBS + C0 + 4 * part) = x;
             } else {
+                // one division per chunk; the row boundary inside the chunk is a compare
                 const float e[4] = {x.x, x.y, x.z, x.w};
+                int env = (4 * k) / ROW, col = 4 * k - env * ROW;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int flat = 4 * k + i;
-                    const int env = flat / ROW, col = flat - env * ROW;
                     s_tile[env * NOBS + C0 + col] = e[i];
+                    if (++col == ROW) {
+                        col = 0;
+                        ++env;
+                    }
                 }
             }
         }
@@ -106,12 +110,15 @@ __device__ __forceinline__ void stage_dof_state(const v4f (&v)[ITERS], float *s_
                 *reinterpret_cast<v2f *>(s_tile + env * NOBS + C_VEL + j) =
                     v2f{vel[0] * dof_vel_scale, vel[1] * dof_vel_scale};
             } else {
+                int env = (2 * k) / D, j = 2 * k - env * D;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int pr = 2 * k + h;
-                    const int env = pr / D, j = pr - env * D;
                     s_tile[env * NOBS + C_POS + j] = unscale(pos[h], s_lim[j], s_lim[D + j]);
                     s_tile[env * NOBS + C_VEL + j] = vel[h] * dof_vel_scale;
+                    if (++j == D) {
+                        j = 0;
+                        ++env;
+                    }
                 }
             }
         }
