@@ -124,3 +124,51 @@ def test_allegro_sharded_over_two_gloo_ranks_equals_one_shard(tmp_path):
     assert np.array_equal(cons[0].view(np.uint32), cons[1].view(np.uint32))  # same bits on every rank
     assert cons[0][0] != 0.0
     np.testing.assert_allclose(cons[0], full["consecutive_successes"], rtol=1e-6)
+
+
+def _shadow_state(n):
+    full = {k: (v.numpy().copy() if v is not None else None)
+            for k, v in synthetic.shadow_state(n, 31, "cpu", "full", True).items()}
+    full["rand"] = np.random.default_rng(2).random((n, 61), dtype=np.float32)
+    return full
+
+
+def _shadow_rank(rank, world, port, n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    oracle.set_num_threads(2)
+    start, count = distributed.env_shard(n, rank, world)
+    mine = _slice_state(_shadow_state(n), start, count)
+    p = synthetic.shadow_params("full")
+    for step in range(3):
+        oracle.shadow_pre_physics(p, mine, count)
+        oracle.shadow_post_physics_shard(p, mine, count)
+        records = distributed.gather_records(torch.from_numpy(mine["workspace"].view(np.uint8)[:16].copy()))
+        oracle.shadow_finalize_shards(p, mine, records.numpy())
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), start=start, count=count,
+             **{k: v for k, v in mine.items() if v is not None})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shadow_sharded_over_three_gloo_ranks_equals_one_shard(tmp_path):
+    """ShadowHand (157-column policy observations + 211-column asymmetric states) over three uneven shards."""
+    n, world = 1000, 3
+    mp.spawn(_shadow_rank, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    full = _shadow_state(n)
+    p = synthetic.shadow_params("full")
+    for step in range(3):
+        oracle.shadow_pre_physics(p, full, n)
+        oracle.shadow_post_physics(p, full, n)
+    assert full["reset"].sum() > 0
+    cons = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        s, c = int(z["start"]), int(z["count"])
+        for k in ("obs", "states", "rew", "reset", "reset_goal", "progress", "successes", "goal_states", "dof_state",
+                  "cur_targets", "prev_targets"):
+            assert np.array_equal(z[k].view(np.uint8), full[k][s:s + c].view(np.uint8)), (r, k)
+        cons.append(z["consecutive_successes"].copy())
+    assert all(np.array_equal(c.view(np.uint32), cons[0].view(np.uint32)) for c in cons)  # same bits on every rank
+    np.testing.assert_allclose(cons[0], full["consecutive_successes"], rtol=1e-6)
