@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(QuantileState *sta
     advance_state(&states[QPASSES - 1], hist_of(states, QPASSES - 1), QPASSES - 1, &s_st, s_wave);
     if (threadIdx.x == 0) {
         const double a = value_of(s_st.prefix[0]), b = value_of(s_st.prefix[1]), w = s_st.weight;
-        const double diff = b - a;  // at::native::lerp
-        const double r = (fabs(w) < 0.5) ? a + w * diff : b - diff * (1.0 - w);
+        // at::native lerp as torch's CPU kernel evaluates it: one fused multiply-add onto the nearer end
+        const double diff = b - a;
+        const double r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
         s_st.result = r;
         states[QPASSES] = s_st;
         states[0].result = r;

@@ -1359,7 +1359,96 @@ double orc_quantile_f64(const double *x, int64_t n, double q)
     int64_t below = (int64_t)ranks, above = (int64_t)ceil(ranks);
     double w = ranks - (double)below, a = s[below], b = s[above], diff = b - a;
     free(s);
-    return (fabs(w) < 0.5) ? a + w * diff : b - diff * (1.0 - w); /* at::native::lerp */
+    /* at::native lerp as the CPU kernel evaluates it: one fused multiply-add onto the nearer end */
+    return (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+}
+
+/* The same quantile as a radix select, in the shape the device runs it (and shards it): the two
+ * neighbouring order statistics are found most significant digit first, 6 passes of 9 + 5 x 11 bits over
+ * an order-preserving integer image of the doubles; every pass first picks, from the complete histogram
+ * of the pass before, the bin that holds each rank.  Shards all-reduce (sum) histogram `pass` between
+ * orc_quantile_histogram(pass) and the next call.  Workspace layout as in include/igx.h: eight 64-byte
+ * states, then per pass two histograms of 2048 uint64 at IGX_QUANTILE_HIST_OFFSET(pass). */
+typedef struct { uint64_t prefix[2], rank[2]; double weight, result; uint64_t n_total, pad; } quantile_state;
+
+static int q_bits(int pass) { return pass == 0 ? 9 : 11; }
+static int q_shift(int pass) { return pass == 0 ? 55 : 55 - 11 * pass; }
+static uint64_t q_key(double x)
+{
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+static double q_value(uint64_t k)
+{
+    uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double x;
+    memcpy(&x, &u, 8);
+    return x;
+}
+static uint64_t *q_hist(void *ws, int pass) { return (uint64_t *)((char *)ws + IGX_QUANTILE_HIST_OFFSET(pass)); }
+
+static void q_advance(const quantile_state *in, const uint64_t *hist, int pass, quantile_state *out)
+{
+    *out = *in;
+    const int bits = q_bits(pass), nb = 1 << bits;
+    const int same = in->prefix[0] == in->prefix[1];
+    for (int r = 0; r < 2; ++r) {
+        const uint64_t *h = hist + ((r == 1 && !same) ? 2048 : 0);
+        uint64_t run = 0, rank = in->rank[r];
+        for (int bin = 0; bin < nb; ++bin) {
+            if (rank >= run && rank < run + h[bin]) {
+                out->prefix[r] = (in->prefix[r] << bits) | (uint64_t)bin;
+                out->rank[r] = rank - run;
+            }
+            run += h[bin];
+        }
+    }
+}
+
+int orc_quantile_begin(void *ws, double q, int64_t n_total)
+{
+    quantile_state *st = (quantile_state *)ws;
+    memset(q_hist(ws, 0), 0, (size_t)(IGX_QUANTILE_HIST_OFFSET(IGX_QUANTILE_PASSES) - IGX_QUANTILE_HIST_OFFSET(0)));
+    double ranks = q * (double)(n_total - 1);
+    int64_t below = (int64_t)ranks, above = (int64_t)ceil(ranks);
+    memset(&st[0], 0, sizeof st[0]);
+    st[0].rank[0] = (uint64_t)below;
+    st[0].rank[1] = (uint64_t)above;
+    st[0].weight = ranks - (double)below;
+    st[0].n_total = (uint64_t)n_total;
+    return 0;
+}
+
+int orc_quantile_histogram(const double *x, int64_t n, void *ws, int32_t pass)
+{
+    quantile_state *st = (quantile_state *)ws;
+    if (pass > 0) q_advance(&st[pass - 1], q_hist(ws, pass - 1), pass - 1, &st[pass]);
+    const quantile_state *cur = &st[pass];
+    uint64_t *hist = q_hist(ws, pass);
+    const int shift = q_shift(pass), bits = q_bits(pass);
+    const int same = cur->prefix[0] == cur->prefix[1];
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t k = q_key(x[i]);
+        uint64_t hi = pass == 0 ? 0 : (k >> (shift + bits));
+        unsigned d = (unsigned)((k >> shift) & ((1u << bits) - 1u));
+        if (hi == cur->prefix[0]) hist[d] += 1;
+        if (!same && hi == cur->prefix[1]) hist[2048 + d] += 1;
+    }
+    return 0;
+}
+
+int orc_quantile_finish(void *ws, double *out)
+{
+    quantile_state *st = (quantile_state *)ws;
+    const int last = IGX_QUANTILE_PASSES - 1;
+    q_advance(&st[last], q_hist(ws, last), last, &st[last + 1]);
+    double a = q_value(st[last + 1].prefix[0]), b = q_value(st[last + 1].prefix[1]), w = st[last + 1].weight;
+    double diff = b - a, r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+    st[last + 1].result = r;
+    st[0].result = r;
+    if (out) *out = r;
+    return 0;
 }
 
 int orc_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n)

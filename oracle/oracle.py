@@ -280,6 +280,31 @@ def quantile_f64(x, q):
     return float(fn(C.c_void_p(x.ctypes.data), C.c_int64(x.size), C.c_double(q)))
 
 
+def quantile_workspace():
+    return np.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, np.int64)
+
+
+def quantile_begin(ws, q, n_total):
+    assert lib().orc_quantile_begin(C.c_void_p(ws.ctypes.data), C.c_double(q), C.c_int64(n_total)) == 0
+
+
+def quantile_histogram(x, ws, p):
+    """Histogram of digit p of this shard's values (after picking the bins of digit p - 1)."""
+    x = np.ascontiguousarray(x, np.float64)
+    assert lib().orc_quantile_histogram(C.c_void_p(x.ctypes.data), C.c_int64(x.size), C.c_void_p(ws.ctypes.data), C.c_int32(p)) == 0
+
+
+def quantile_hist_view(ws, p):
+    off = _abi.IGX_QUANTILE_HIST_OFFSET(p) // 8
+    return ws[off:off + 2 * 2048]
+
+
+def quantile_finish(ws):
+    out = C.c_double(0.0)
+    assert lib().orc_quantile_finish(C.c_void_p(ws.ctypes.data), C.byref(out)) == 0
+    return out.value
+
+
 def imitate_args(arrays, num_frames, quantile, distance_floor, death_cost, n_total):
     """igx_imitate_args over numpy arrays: motion [F,8] f64, target_pose_idx [n] i64, pose_diff [n] f64."""
     im = _abi.ImitateArgs(num_frames=num_frames, quantile=quantile, distance_floor=distance_floor,

@@ -172,3 +172,37 @@ def test_shadow_sharded_over_three_gloo_ranks_equals_one_shard(tmp_path):
         cons.append(z["consecutive_successes"].copy())
     assert all(np.array_equal(c.view(np.uint32), cons[0].view(np.uint32)) for c in cons)  # same bits on every rank
     np.testing.assert_allclose(cons[0], full["consecutive_successes"], rtol=1e-6)
+
+
+def _quantile_rank(rank, world, port, n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    x = np.random.default_rng(11).standard_normal(n) ** 3
+    x[: n // 5] = 0.75  # ties across the shard boundary
+    start, count = distributed.env_shard(n, rank, world)
+    results = []
+    for q in (0.99, 0.5, 0.0, 1.0):
+        ws = oracle.quantile_workspace()
+        oracle.quantile_begin(ws, q, n)          # every rank with the GLOBAL count
+        for p in range(6):
+            oracle.quantile_histogram(x[start:start + count], ws, p)
+            hist = torch.from_numpy(oracle.quantile_hist_view(ws, p))   # a view: reduced in place
+            dist.all_reduce(hist)
+        results.append(oracle.quantile_finish(ws))
+    np.save(os.path.join(outdir, "q%d.npy" % rank), np.array(results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_quantile_sharded_over_two_gloo_ranks_equals_torch(tmp_path):
+    """The one real exchange of the imitation path: per-pass histograms all-reduced over the ranks make
+    every rank select the same order statistics as torch.quantile over all environments."""
+    n, world = 50001, 2
+    mp.spawn(_quantile_rank, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    x = np.random.default_rng(11).standard_normal(n) ** 3
+    x[: n // 5] = 0.75
+    want = np.array([float(torch.quantile(torch.from_numpy(x), q)) for q in (0.99, 0.5, 0.0, 1.0)])
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "q%d.npy" % r))
+        assert np.array_equal(got, want), (r, got, want)

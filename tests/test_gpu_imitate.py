@@ -58,6 +58,40 @@ def test_quantile_sharded_equals_whole():
         assert float(ws.view(torch.float64)[5]) == want
 
 
+def test_quantile_random_ranks_and_weights_equal_torch():
+    """Random (n, q): the interpolation is torch's fused multiply-add onto the nearer order statistic."""
+    rng = np.random.default_rng(6)
+    ws = _ws()
+    for _ in range(150):
+        n = int(rng.integers(1, 3000))
+        x = torch.from_numpy(rng.standard_normal(n) ** 3)
+        q = float(rng.random())
+        assert float(ops.quantile_f64(x.to(DEV), q, ws)) == float(torch.quantile(x, q)), (n, q)
+
+
+def test_quantile_passes_match_the_cpu_restatement():
+    """Every pass of the device radix select leaves the histograms and states of the CPU restatement."""
+    from isaacgym_amd import _lib
+    from oracle import oracle
+    import ctypes as C
+    n = 70001
+    x = torch.randn(n, device=DEV, dtype=torch.float64) ** 3
+    x[:9000] = 0.5
+    lib, st = _lib.lib(), _lib.current_stream(torch.device(DEV))
+    ws, ows = _ws(), oracle.quantile_workspace()
+    _lib.check(lib.igx_quantile_begin(_lib.tensor_ptr(ws), C.c_double(0.99), C.c_int64(n), st))
+    oracle.quantile_begin(ows, 0.99, n)
+    xh = x.cpu().numpy()
+    for p in range(_abi.IGX_QUANTILE_PASSES):
+        _lib.check(lib.igx_quantile_histogram(_lib.tensor_ptr(x), C.c_int64(n), _lib.tensor_ptr(ws), C.c_int32(p), st))
+        oracle.quantile_histogram(xh, ows, p)
+        off = _abi.IGX_QUANTILE_HIST_OFFSET(p) // 8
+        assert np.array_equal(ws[off:off + 4096].cpu().numpy(), ows[off:off + 4096]), "histogram of pass %d" % p
+        assert np.array_equal(ws[8 * p:8 * p + 4].cpu().numpy(), ows[8 * p:8 * p + 4]), "prefix / rank before pass %d" % p
+    _lib.check(lib.igx_quantile_finish(_lib.tensor_ptr(ws), None, st))
+    assert float(ws.view(torch.float64)[5]) == oracle.quantile_finish(ows) == float(torch.quantile(x.cpu(), 0.99))
+
+
 def test_ant_imitate_golden():
     g = H.load_golden("ant_imitate")
     ws = _ws()
