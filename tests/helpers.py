@@ -179,9 +179,10 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         for k in ("reset", "reset_goal", "progress", "randomize"):
             assert np.array_equal(to_np(b[k]), g[k][t]), what + k
         assert bit_equal_fraction(to_np(b["successes"]), g["successes"][t]) == 1.0, what + "successes"
-        assert_close(to_np(b["obs"]), g["obs"][t], what=what + "obs")
+        # observations are copies, scalings and quaternion products: exact arithmetic, bit for bit
+        assert bit_equal_fraction(to_np(b["obs"]), g["obs"][t]) == 1.0, what + "obs"
         if asym:
-            assert_close(to_np(b["states"]), g["states"][t], what=what + "states")
+            assert bit_equal_fraction(to_np(b["states"]), g["states"][t]) == 1.0, what + "states"
         # reward: -10*dist + 1/(|rot_dist|+0.1) (+250 bonus): natural scale 1
         assert_close(to_np(b["rew"]), g["rew"][t], what=what + "rew")
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
@@ -273,9 +274,10 @@ def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         for k in ("reset", "reset_goal", "progress", "randomize"):
             assert np.array_equal(to_np(b[k]), g[k][t]), what + k
         assert bit_equal_fraction(to_np(b["successes"]), g["successes"][t]) == 1.0, what + "successes"
-        assert_close(to_np(b["obs"]), g["obs"][t], what=what + "obs")
+        # observations are copies, scalings and quaternion products: exact arithmetic, bit for bit
+        assert bit_equal_fraction(to_np(b["obs"]), g["obs"][t]) == 1.0, what + "obs"
         if asym:
-            assert_close(to_np(b["states"]), g["states"][t], what=what + "states")
+            assert bit_equal_fraction(to_np(b["states"]), g["states"][t]) == 1.0, what + "states"
         assert_close(to_np(b["rew"]), g["rew"][t], what=what + "rew")
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
