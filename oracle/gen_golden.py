@@ -291,10 +291,16 @@ def _loco_inputs(t, N, D, S, g, z_mean, z_std, with_force):
         t.dof_force_tensor = torch.randn(N, D, generator=g) * 30
 
 
-def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T):
+def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_over=None, dt=None, targets=None,
+              start_rotation=None):
+    """env_over / dt / targets / start_rotation: non-default values, so that a recording also pins how every
+    parameter enters the arithmetic (the default files only exercise the YAML defaults)."""
     _install_gym_stubs()
     mod = ref_shim.load(modname)
     cfg = _cfg(cfgname)
+    cfg["env"].update(env_over or {})
+    if dt is not None:
+        cfg["sim"]["dt"] = dt
     Base = getattr(mod, clsname)
 
     class Fake(Base):
@@ -305,6 +311,15 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T):
     t = Fake()
     z_mean, z_std = (1.34, 0.3) if humanoid else (0.55, 0.1)
     _loco_common(t, cfg, N, D, g, z_mean)
+    if targets is not None:
+        t.targets = torch.tensor(targets, dtype=torch.float).repeat(N, 1)
+        t.potentials = -torch.norm((t.targets - t.initial_root_states[:, 0:3]) * torch.tensor([1.0, 1.0, 0.0]), p=2, dim=-1) / t.dt
+        t.prev_potentials = t.potentials.clone()
+    if start_rotation is not None:
+        tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+        q = torch.tensor(start_rotation, dtype=torch.float)
+        t.start_rotation = q / q.norm()
+        t.inv_start_rot = tj.quat_conjugate(t.start_rotation).repeat(N, 1)
     nobs = 108 if humanoid else 60
     t.obs_buf = torch.zeros(N, nobs)
     if humanoid:
@@ -326,7 +341,8 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T):
             "initial_root_states": t.initial_root_states.numpy().copy(),
             "initial_dof_pos": t.initial_dof_pos.numpy().copy(),
             "dof_limits_lower": t.dof_limits_lower.numpy().copy(),
-            "dof_limits_upper": t.dof_limits_upper.numpy().copy()}
+            "dof_limits_upper": t.dof_limits_upper.numpy().copy(),
+            "targets": t.targets[0].numpy().copy(), "inv_start_rot": t.inv_start_rot[0].numpy().copy()}
     if humanoid:
         init["motor_efforts"] = t.motor_efforts.numpy().copy()
     torch.manual_seed(seed + 100)
@@ -566,6 +582,21 @@ def gen_ant(seed=1, N=449, T=4):
 
 def gen_humanoid(seed=2, N=211, T=4):
     _gen_loco("humanoid", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, seed, N, T)
+
+
+ALT_ENV = dict(dofVelocityScale=0.37, contactForceScale=0.023, upWeight=0.17, headingWeight=0.61, actionsCost=0.013,
+               energyCost=0.071, jointsAtLimitCost=0.29, deathCost=-3.5, episodeLength=700)
+
+
+def gen_loco_alt():
+    """Ant and Humanoid with every tunable off its YAML default, another time step, another target and a
+    tilted start rotation."""
+    _gen_loco("ant_alt", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, 71, 150, 3,
+              env_over=dict(ALT_ENV, terminationHeight=0.47), dt=0.0125, targets=[-300.0, 450.0, 2.0],
+              start_rotation=[0.1, -0.2, 0.3, 0.9])
+    _gen_loco("humanoid_alt", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, 72, 90, 3,
+              env_over=dict(ALT_ENV, terminationHeight=1.1, angularVelocityScale=0.4), dt=0.02,
+              targets=[120.0, -80.0, 0.0], start_rotation=[0.0, 0.3, 0.0, 0.95])
 
 
 # --------------------------------------------------------------------------
@@ -1617,7 +1648,7 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -102,6 +102,14 @@ def test_humanoid_golden():
     _golden_loco("humanoid", ops.humanoid_step, 108, True)
 
 
+def test_ant_golden_with_every_parameter_changed():
+    _golden_loco("ant_alt", ops.ant_step, 60, False)
+
+
+def test_humanoid_golden_with_every_parameter_changed():
+    _golden_loco("humanoid_alt", ops.humanoid_step, 108, True)
+
+
 def _vs_oracle(spec, step, ostep, n, with_rand, steps=2):
     p = synthetic.loco_params(spec, seed=1234, rng_offset=9)
     t = synthetic.loco_state(spec, n, 11, DEV, with_rand)

@@ -86,3 +86,13 @@ def test_ant_oracle_matches_reference():
 
 def test_humanoid_oracle_matches_reference():
     _run_loco("humanoid", oracle.humanoid_step, 108, True)
+
+
+def test_ant_oracle_matches_reference_with_every_parameter_changed():
+    """Recorded with every scale, weight, cost, the termination height, dt, the target
+    and the start rotation off their YAML values: pins where each one enters."""
+    _run_loco("ant_alt", oracle.ant_step, 60, False)
+
+
+def test_humanoid_oracle_matches_reference_with_every_parameter_changed():
+    _run_loco("humanoid_alt", oracle.humanoid_step, 108, True)
