@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 using v4f = float __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -111,19 +112,35 @@ static double time_ms(F f, int iters)
     return ms / iters;
 }
 
-int main()
+// argv[1] = "random": fill every buffer with random finite floats instead of zeros
+// (the data pattern changes what the memory system sustains)
+int main(int argc, char **argv)
 {
     const int64_t N = 1 << 20, ntiles = N / 64;
-    const int NS = 3;
+    const int NS = 4;
+    const bool random = argc > 1 && std::string(argv[1]) == "random";
+    std::vector<uint32_t> host;
+    if (random) {
+        host.resize((size_t)N * 60 + 1024);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (auto &w : host) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            w = ((uint32_t)(x >> 32) & 0x007FFFFFu) | 0x3F000000u | ((uint32_t)x & 0x80000000u);  // +-[0.5, 1)
+        }
+    }
     Bufs s[NS];
     for (int i = 0; i < NS; ++i) {
-        auto A = [&](size_t bytes) { void *p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0, bytes)); return p; };
+        auto A = [&](size_t bytes) {
+            void *p; CHECK(hipMalloc(&p, bytes));
+            if (random) CHECK(hipMemcpy(p, (const char *)host.data() + 4 * ((i * 977 + bytes / 64) % 1024), bytes, hipMemcpyHostToDevice));
+            else CHECK(hipMemset(p, 0, bytes));
+            return p; };
         s[i].root = (float *)A(N * 13 * 4); s[i].dof = (float *)A(N * 16 * 4); s[i].sens = (float *)A(N * 24 * 4); s[i].act = (float *)A(N * 8 * 4);
         s[i].pot = (float *)A(N * 4); s[i].prev = (float *)A(N * 4); s[i].up = (float *)A(N * 12); s[i].head = (float *)A(N * 12); s[i].rew = (float *)A(N * 4);
         s[i].obs = (float *)A(N * 240); s[i].reset = (int64_t *)A(N * 8); s[i].prog = (int64_t *)A(N * 8); s[i].rnd = (int64_t *)A(N * 8);
     }
     const double bytes = 556.0 * N;
-    printf("{");
+    printf("{\"data\": \"%s\", ", random ? "random" : "zeros");
     bool first = true;
     auto emit = [&](const std::string &name, double ms) { printf("%s\"%s\": [%.1f, %.0f]", first ? "" : ", ", name.c_str(), ms * 1e3, bytes / ms / 1e6); first = false; fflush(stdout); };
 #define RUN(TPB, PERSIST, NT, GRID, NAME) emit(NAME, time_ms([&](int i) { hipLaunchKernelGGL((skel<TPB, PERSIST, NT>), dim3(GRID), dim3(TPB), 0, 0, s[i % NS], ntiles); }, 30))
