@@ -120,3 +120,17 @@ def test_every_entry_point_rejects_null_structs():
     p = _abi.AmpParams(num_amp_obs_steps=1)
     b = _abi.AmpBuffers()
     assert lib.igx_humanoid_amp_step(ctypes.byref(p), ctypes.byref(b), 4, None) == _abi.IGX_E_PARAM
+
+
+def test_binding_stub_in_the_integration_guide_matches_the_header():
+    """The ctypes stub a maintainer of the reference would paste must describe today's structs."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# isaacgymenvs/utils/igx_binding\.py.*?)```", text, flags=re.S).group(1)
+    block = block.replace("/path/to/libigx.so", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(block, "igx_binding.py", "exec"), ns)
+    for mine, theirs in ((_abi.LocoParams, ns["LocoParams"]), (_abi.LocoBuffers, ns["LocoBuffers"])):
+        assert ctypes.sizeof(mine) == ctypes.sizeof(theirs)
+        assert [f[0] for f in mine._fields_] == [f[0] for f in theirs._fields_]
+        for f in mine._fields_:
+            assert getattr(mine, f[0]).offset == getattr(theirs, f[0]).offset, f[0]

@@ -1,0 +1,97 @@
+"""The step entry points enqueue kernels on the caller's stream and nothing else: no
+allocation, no copy through the host, no synchronisation.  The proof is that they can be
+recorded into a HIP graph on a capturing stream and that replays of the graph on new inputs
+give the bits of an eager call on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from isaacgym_amd import _abi, ops, synthetic  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _clone(t):
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in t.items()}
+
+
+def _same_bits(a, b, keys):
+    for k in keys:
+        if torch.is_tensor(a.get(k)):
+            x, y = a[k], b[k]
+            assert torch.equal(x.view(torch.uint8) if x.dtype != torch.bool else x,
+                               y.view(torch.uint8) if y.dtype != torch.bool else y), k
+
+
+def _capture(fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # the first call loads the code object: keep that out of the capture
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+@pytest.mark.parametrize("spec,step", [(synthetic.ANT, ops.ant_step), (synthetic.HUMANOID, ops.humanoid_step)])
+def test_loco_step_replays_from_a_graph(spec, step):
+    n = 20011
+    p = synthetic.loco_params(spec, seed=8, rng_offset=5)
+    static = synthetic.loco_state(spec, n, 1, DEV, with_rand=True)  # caller-supplied uniforms: nothing baked into the launch
+    static["obs_clamped"] = torch.zeros(n, spec["num_obs"], device=DEV)
+    static["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
+    p.clip_obs = 1.5
+    scratch = _clone(static)
+    g = _capture(lambda: step(p, static, n))
+    for s in range(3):
+        fresh = synthetic.loco_state(spec, n, 50 + s, DEV, with_rand=True)
+        fresh["reset"][::7] = 1
+        for k, v in fresh.items():
+            static[k].copy_(v)
+            scratch[k].copy_(v)
+        g.replay()
+        step(p, scratch, n)
+        torch.cuda.synchronize()
+        _same_bits(static, scratch, static.keys())
+
+
+def test_hand_post_physics_with_its_reduction_replays_from_a_graph():
+    n = 9001
+    p = synthetic.allegro_params("full_state", seed=2, rng_offset=1)
+    static = synthetic.allegro_state(n, 5, DEV, "full_state", True)
+    scratch = _clone(static)
+    g = _capture(lambda: ops.allegro_post_physics(p, static, n))
+    for s in range(2):
+        fresh = synthetic.allegro_state(n, 60 + s, DEV, "full_state", True)
+        for k, v in fresh.items():
+            if torch.is_tensor(v):
+                static[k].copy_(v)
+                scratch[k].copy_(v)
+        g.replay()
+        ops.allegro_post_physics(p, scratch, n)
+        torch.cuda.synchronize()
+        _same_bits(static, scratch, [k for k in static if k != "workspace"])
+
+
+def test_quantile_select_replays_from_a_graph():
+    n = 70001
+    x = torch.zeros(n, dtype=torch.float64, device=DEV)
+    ws = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+    out = {}
+
+    def run():
+        out["q"] = ops.quantile_f64(x, 0.9, ws)
+
+    g = _capture(run)
+    gen = torch.Generator().manual_seed(3)
+    for s in range(3):
+        v = torch.rand(n, dtype=torch.float64, generator=gen) * (s + 1)
+        x.copy_(v)
+        g.replay()
+        torch.cuda.synchronize()
+        assert float(out["q"]) == float(torch.quantile(v, 0.9))
