@@ -720,6 +720,68 @@ int igx_exp_map_to_quat(const float *e, float *out, int64_t n, igx_stream_t stre
 int igx_quat_to_tan_norm(const float *q, float *out, int64_t n, igx_stream_t stream);
 /* :656-667 calc_heading_quat_inv(q) -> [n,4] */
 int igx_calc_heading_quat_inv(const float *q, float *out, int64_t n, igx_stream_t stream);
+/* :65-67 normalize(x [n,d]): x / clamp(||x||, 1e-9); d = 3 or 4 */
+int igx_normalize(const float *x, float *out, int64_t n, int32_t d, igx_stream_t stream);
+/* :113-115 quat_unit(a) = normalize of [n,4] */
+int igx_quat_unit(const float *a, float *out, int64_t n, igx_stream_t stream);
+/* :70-77 quat_apply(a [n,4], b [n,3]) -> [n,3]; tf_vector (:142-144) is the same function */
+int igx_quat_apply(const float *a, const float *b, float *out, int64_t n, igx_stream_t stream);
+/* :131-134 tf_inverse(q, t) -> (quat_conjugate(q) [n,4], -quat_apply(q_inv, t) [n,3]) */
+int igx_tf_inverse(const float *q, const float *t, float *q_out, float *t_out, int64_t n, igx_stream_t stream);
+/* :137-139 tf_apply(q, t, v) = quat_apply(q, v) + t */
+int igx_tf_apply(const float *q, const float *t, const float *v, float *out, int64_t n, igx_stream_t stream);
+/* :147-149 tf_combine(q1, t1, q2, t2) -> (quat_mul(q1, q2), quat_apply(q1, t2) + t1) */
+int igx_tf_combine(const float *q1, const float *t1, const float *q2, const float *t2, float *q_out, float *t_out,
+                   int64_t n, igx_stream_t stream);
+/* :168-172 copysign(a, b [n]) = |a| * sign(b)  (0 where b is +-0 or NaN, as torch.sign) */
+int igx_copysign(float a, const float *b, float *out, int64_t n, igx_stream_t stream);
+/* :175-195 get_euler_xyz(q) -> roll, pitch, yaw [n] each, in [0, 2 pi) */
+int igx_get_euler_xyz(const float *q, float *roll, float *pitch, float *yaw, int64_t n, igx_stream_t stream);
+/* :198-212 quat_from_euler_xyz(roll, pitch, yaw [n]) -> [n,4] */
+int igx_quat_from_euler_xyz(const float *roll, const float *pitch, const float *yaw, float *out, int64_t n,
+                            igx_stream_t stream);
+/* :563-568 euler_xyz_to_exp_map(roll, pitch, yaw [n]) -> [n,3] */
+int igx_euler_xyz_to_exp_map(const float *roll, const float *pitch, const float *yaw, float *out, int64_t n,
+                             igx_stream_t stream);
+/* :215-218 torch_rand_float(lower, upper, shape): (upper - lower) * u + lower over `count` elements.
+ * uniforms: the torch.rand draws in [0,1) to reproduce a torch sequence, or NULL for the library's
+ * Philox4x32-10 stream keyed by (seed, rng_offset, element). */
+int igx_torch_rand_float(double lower, double upper, const float *uniforms, uint64_t seed, uint64_t rng_offset,
+                         float *out, int64_t count, igx_stream_t stream);
+/* :248-263 compute_heading_and_up(torso_rotation [n,4], inv_start_rot [n,4], to_target [n,3], vec0 [n,3],
+ * vec1 [n,3], up_idx) -> torso_quat [n,4], up_proj [n], heading_proj [n], up_vec [n,3], heading_vec [n,3] */
+int igx_compute_heading_and_up(const float *torso_rotation, const float *inv_start_rot, const float *to_target,
+                               const float *vec0, const float *vec1, int32_t up_idx, float *torso_quat,
+                               float *up_proj, float *heading_proj, float *up_vec, float *heading_vec, int64_t n,
+                               igx_stream_t stream);
+/* :266-277 compute_rot(torso_quat [n,4], velocity, ang_velocity, targets, torso_positions [n,3] each)
+ * -> vel_loc [n,3], angvel_loc [n,3], roll, pitch, yaw, angle_to_target [n] each */
+int igx_compute_rot(const float *torso_quat, const float *velocity, const float *ang_velocity, const float *targets,
+                    const float *torso_positions, float *vel_loc, float *angvel_loc, float *roll, float *pitch,
+                    float *yaw, float *angle_to_target, int64_t n, igx_stream_t stream);
+/* :280-285 quat_axis(q, axis in 0..2) = quat_rotate(q, unit vector of that axis) */
+int igx_quat_axis(const float *q, int32_t axis, float *out, int64_t n, igx_stream_t stream);
+/* :292-310 scale_transform, :313-331 unscale_transform, :333-348 saturate: x [n,d] against lower / upper [d] */
+int igx_scale_transform(const float *x, const float *lower, const float *upper, float *out, int64_t n, int32_t d,
+                        igx_stream_t stream);
+int igx_unscale_transform(const float *x, const float *lower, const float *upper, float *out, int64_t n, int32_t d,
+                          igx_stream_t stream);
+int igx_saturate(const float *x, const float *lower, const float *upper, float *out, int64_t n, int32_t d,
+                 igx_stream_t stream);
+/* :354-373 quat_diff_rad(a, b) -> [n] */
+int igx_quat_diff_rad(const float *a, const float *b, float *out, int64_t n, igx_stream_t stream);
+/* :376-395 local_to_world_space(pos_offset_local [n,3], pose_global [n,7] = pos 3 + quat 4) -> [n,3] */
+int igx_local_to_world_space(const float *pos_offset_local, const float *pose_global, float *out, int64_t n,
+                             igx_stream_t stream);
+/* :423-444 quat_to_angle_axis(q) -> angle [n], axis [n,3] */
+int igx_quat_to_angle_axis(const float *q, float *angle, float *axis, int64_t n, igx_stream_t stream);
+/* :446-452 angle_axis_to_exp_map(angle [n], axis [n,3]) -> [n,3] */
+int igx_angle_axis_to_exp_map(const float *angle, const float *axis, float *out, int64_t n, igx_stream_t stream);
+/* :570-587 exp_map_to_angle_axis(exp_map [n,3]) -> angle [n], axis [n,3] */
+int igx_exp_map_to_angle_axis(const float *exp_map, float *angle, float *axis, int64_t n, igx_stream_t stream);
+/* :630-641 calc_heading(q) -> [n]; :643-654 calc_heading_quat(q) -> [n,4] */
+int igx_calc_heading(const float *q, float *out, int64_t n, igx_stream_t stream);
+int igx_calc_heading_quat(const float *q, float *out, int64_t n, igx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,8 +76,21 @@ for _name, _nin in (("igx_quat_mul", 2), ("igx_quat_conjugate", 1), ("igx_quat_r
                     ("igx_normalize_angle", 1), ("igx_quat_to_exp_map", 1), ("igx_exp_map_to_quat", 1),
                     ("igx_quat_to_tan_norm", 1), ("igx_calc_heading_quat_inv", 1)):
     SYMBOLS[_name] = (C.c_int, [_P] * (_nin + 1) + [_I64, _P])
-for _name in ("igx_scale", "igx_unscale", "igx_tensor_clamp"):
+for _name in ("igx_scale", "igx_unscale", "igx_tensor_clamp", "igx_scale_transform", "igx_unscale_transform",
+              "igx_saturate"):
     SYMBOLS[_name] = (C.c_int, [_P, _P, _P, _P, _I64, C.c_int32, _P])
+# (name, number of input arrays + output arrays): all pointers, then n and the stream
+for _name, _narr in (("igx_quat_unit", 2), ("igx_quat_apply", 3), ("igx_tf_inverse", 4), ("igx_tf_apply", 4),
+                     ("igx_tf_combine", 6), ("igx_get_euler_xyz", 4), ("igx_quat_from_euler_xyz", 4),
+                     ("igx_euler_xyz_to_exp_map", 4), ("igx_compute_rot", 11), ("igx_quat_diff_rad", 3),
+                     ("igx_local_to_world_space", 3), ("igx_quat_to_angle_axis", 3), ("igx_angle_axis_to_exp_map", 3),
+                     ("igx_exp_map_to_angle_axis", 3), ("igx_calc_heading", 2), ("igx_calc_heading_quat", 2)):
+    SYMBOLS[_name] = (C.c_int, [_P] * _narr + [_I64, _P])
+SYMBOLS["igx_normalize"] = (C.c_int, [_P, _P, _I64, C.c_int32, _P])
+SYMBOLS["igx_copysign"] = (C.c_int, [C.c_float, _P, _P, _I64, _P])
+SYMBOLS["igx_quat_axis"] = (C.c_int, [_P, C.c_int32, _P, _I64, _P])
+SYMBOLS["igx_torch_rand_float"] = (C.c_int, [C.c_double, C.c_double, _P, C.c_uint64, C.c_uint64, _P, _I64, _P])
+SYMBOLS["igx_compute_heading_and_up"] = (C.c_int, [_P] * 5 + [C.c_int32] + [_P] * 5 + [_I64, _P])
 
 
 class IgxError(RuntimeError):
@@ -203,6 +216,19 @@ def call_rowwise(symbol, inputs, out, n):
             raise ValueError("all tensors must live on %s" % dev)
     with torch.cuda.device(dev):
         rc = getattr(lib(), symbol)(*ptrs, C.c_int64(n), current_stream(dev))
+    check(rc)
+
+
+def call_arrays(symbol, inputs, outputs, n, before=(), between=()):
+    """symbol(*before, inputs..., *between, outputs..., n, stream) on contiguous fp32 device tensors."""
+    dev = outputs[0].device
+    for t in list(inputs) + list(outputs):
+        if t.device != dev:
+            raise ValueError("all tensors must live on %s" % dev)
+    args = (list(before) + [tensor_ptr(t, torch.float32) for t in inputs] + list(between) +
+            [tensor_ptr(t, torch.float32) for t in outputs])
+    with torch.cuda.device(dev):
+        rc = getattr(lib(), symbol)(*args, C.c_int64(n), current_stream(dev))
     check(rc)
 
 

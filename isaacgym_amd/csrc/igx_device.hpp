@@ -201,6 +201,51 @@ __device__ __forceinline__ f4 calc_heading_quat_inv(f4 q)
     return quat_from_angle_axis(-calc_heading(q), f3{0.0f, 0.0f, 1.0f});
 }
 
+// :70-77 quat_apply: b + w * t + xyz x t with t = 2 (xyz x b)
+__device__ __forceinline__ f3 quat_apply(f4 a, f3 b)
+{
+    const f3 xyz{a.x, a.y, a.z};
+    const f3 c = cross3(xyz, b);
+    const f3 t{c.x * 2.0f, c.y * 2.0f, c.z * 2.0f};
+    const f3 u = cross3(xyz, t);
+    return f3{b.x + a.w * t.x + u.x, b.y + a.w * t.y + u.y, b.z + a.w * t.z + u.z};
+}
+
+// :168-172 copysign(a, b) = |a| * sign(b); torch.sign gives 0 for +-0 and for NaN
+__device__ __forceinline__ float copysign_sign(float a, float b)
+{
+    return fabsf(a) * (float)((int)(0.0f < b) - (int)(b < 0.0f));
+}
+
+// :184-187, :195 the pitch of get_euler_xyz
+__device__ __forceinline__ float euler_pitch(f4 q)
+{
+    const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+    const float pitch = (fabsf(sinp) >= 1.0f) ? copysign_sign(1.5707964f, sinp) : asinf(sinp);
+    return remainder_2pi(pitch);
+}
+
+// :198-212 quat_from_euler_xyz
+__device__ __forceinline__ f4 quat_from_euler_xyz(float roll, float pitch, float yaw)
+{
+    const float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
+    const float cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
+    const float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+    return f4{cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp,
+              cy * cr * cp + sy * sr * sp};
+}
+
+// :570-587 exp_map_to_angle_axis (masked like the reference's where)
+__device__ __forceinline__ void exp_map_to_angle_axis(f3 e, float &angle, f3 &axis)
+{
+    const float n = norm3(e);
+    axis = f3{e.x / n, e.y / n, e.z / n};
+    angle = normalize_angle(n);
+    const bool mask = angle > 1e-5f;
+    angle = mask ? angle : 0.0f;
+    axis = mask ? axis : f3{0.0f, 0.0f, 1.0f};
+}
+
 // torch.clamp(x, lo, hi): NaN stays NaN (lo <= hi)
 __device__ __forceinline__ float clamp1(float x, float lo, float hi)
 {

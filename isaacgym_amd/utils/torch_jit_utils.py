@@ -5,6 +5,9 @@ Same names, argument order and result shapes as the reference
 (IsaacGymEnvs/isaacgymenvs/utils/torch_jit_utils.py; line numbers at each
 function).  Inputs are fp32 device tensors; quaternions are xyzw.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 
 from .. import _lib
@@ -97,6 +100,169 @@ def unscale(x, lower, upper):  # :239-241
 
 def tensor_clamp(t, min_t, max_t):  # :228-230
     return _affine("igx_tensor_clamp", t, min_t, max_t)
+
+
+def _run_multi(symbol, ins, widths, out_widths, out_shapes, before=(), between=()):
+    """Several input arrays -> several output arrays, one launch."""
+    rows = [_rows(t, w) for t, w in zip(ins, widths)]
+    n = rows[0].shape[0]
+    for r in rows:
+        if r.shape[0] != n:
+            raise ValueError("batch sizes differ: %s" % [tuple(r.shape) for r in rows])
+    dev = rows[0].device
+    outs = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in out_widths]
+    _lib.call_arrays(symbol, rows, outs, n, before=before, between=between)
+    return tuple(o.view(sh) for o, sh in zip(outs, out_shapes))
+
+
+def normalize(x, eps: float = 1e-9):  # :65-67 (rows of 3 or 4 floats; eps is the reference's default)
+    if eps != 1e-9:
+        raise ValueError("the kernel implements the reference's default eps = 1e-9")
+    d = x.shape[-1]
+    xs = _rows(x, d)
+    out = torch.empty_like(xs)
+    dev = xs.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_normalize(_lib.tensor_ptr(xs, torch.float32), _lib.tensor_ptr(out, torch.float32),
+                                      C.c_int64(xs.shape[0]), C.c_int32(d), _lib.current_stream(dev))
+    _lib.check(rc)
+    return out.view(x.shape)
+
+
+def quat_unit(a):  # :113-115
+    return _run_multi("igx_quat_unit", (a,), (4,), (4,), (a.shape,))[0]
+
+
+def quat_apply(a, b):  # :70-77
+    return _run_multi("igx_quat_apply", (a, b), (4, 3), (3,), (b.shape,))[0]
+
+
+def tf_inverse(q, t):  # :131-134
+    return _run_multi("igx_tf_inverse", (q, t), (4, 3), (4, 3), (q.shape, t.shape))
+
+
+def tf_apply(q, t, v):  # :137-139
+    return _run_multi("igx_tf_apply", (q, t, v), (4, 3, 3), (3,), (v.shape,))[0]
+
+
+def tf_vector(q, v):  # :142-144
+    return quat_apply(q, v)
+
+
+def tf_combine(q1, t1, q2, t2):  # :147-149
+    return _run_multi("igx_tf_combine", (q1, t1, q2, t2), (4, 3, 4, 3), (4, 3), (q1.shape, t1.shape))
+
+
+def get_basis_vector(q, v):  # :152-154
+    return quat_rotate(q, v)
+
+
+def get_axis_params(value, axis_idx, x_value=0., dtype=float, n_dims=3):  # :157-165 (host-side list, as in the reference)
+    zs = np.zeros((n_dims,))
+    assert axis_idx < n_dims, "the axis dim should be within the vector dimensions"
+    zs[axis_idx] = 1.
+    params = np.where(zs == 1., value, zs)
+    params[0] = x_value
+    return list(params.astype(dtype))
+
+
+def copysign(a: float, b):  # :168-172
+    return _run_multi("igx_copysign", (b.unsqueeze(-1),), (1,), (1,), (b.shape,), before=(C.c_float(a),))[0]
+
+
+def get_euler_xyz(q):  # :175-195
+    sh = q.shape[:-1]
+    return _run_multi("igx_get_euler_xyz", (q,), (4,), (1, 1, 1), (sh, sh, sh))
+
+
+def quat_from_euler_xyz(roll, pitch, yaw):  # :198-212
+    return _run_multi("igx_quat_from_euler_xyz", (roll.unsqueeze(-1), pitch.unsqueeze(-1), yaw.unsqueeze(-1)), (1, 1, 1),
+                      (4,), (roll.shape + (4,),))[0]
+
+
+def euler_xyz_to_exp_map(roll, pitch, yaw):  # :563-568
+    return _run_multi("igx_euler_xyz_to_exp_map", (roll.unsqueeze(-1), pitch.unsqueeze(-1), yaw.unsqueeze(-1)), (1, 1, 1),
+                      (3,), (roll.shape + (3,),))[0]
+
+
+def torch_rand_float(lower, upper, shape, device, uniforms=None, seed=0, rng_offset=0):  # :215-218
+    """(upper - lower) * u + lower.  The draws come from `uniforms` (what torch.rand(*shape) returned, to reproduce
+    a torch sequence) or, without it, from the library's counter-based generator keyed by (seed, rng_offset)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    u = None
+    if uniforms is not None:
+        if tuple(uniforms.shape) != tuple(shape):
+            raise ValueError("uniforms must have the requested shape")
+        u = uniforms.contiguous().float()
+    dev = out.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_torch_rand_float(C.c_double(lower), C.c_double(upper), _lib.tensor_ptr(u), C.c_uint64(seed),
+                                             C.c_uint64(rng_offset), _lib.tensor_ptr(out), C.c_int64(out.numel()),
+                                             _lib.current_stream(dev))
+    _lib.check(rc)
+    return out
+
+
+def compute_heading_and_up(torso_rotation, inv_start_rot, to_target, vec0, vec1, up_idx: int):  # :248-263
+    n = torso_rotation.shape[0]
+    return _run_multi("igx_compute_heading_and_up", (torso_rotation, inv_start_rot, to_target, vec0, vec1),
+                      (4, 4, 3, 3, 3), (4, 1, 1, 3, 3), ((n, 4), (n,), (n,), (n, 3), (n, 3)),
+                      between=(C.c_int32(up_idx),))
+
+
+def compute_rot(torso_quat, velocity, ang_velocity, targets, torso_positions):  # :266-277
+    n = torso_quat.shape[0]
+    return _run_multi("igx_compute_rot", (torso_quat, velocity, ang_velocity, targets, torso_positions), (4, 3, 3, 3, 3),
+                      (3, 3, 1, 1, 1, 1), ((n, 3), (n, 3), (n,), (n,), (n,), (n,)))
+
+
+def quat_axis(q, axis: int = 0):  # :280-285
+    return _run_multi("igx_quat_axis", (q,), (4,), (3,), ((q.shape[0], 3),), between=(C.c_int32(axis),))[0]
+
+
+def scale_transform(x, lower, upper):  # :292-310
+    return _affine("igx_scale_transform", x, lower, upper)
+
+
+def unscale_transform(x, lower, upper):  # :313-331
+    return _affine("igx_unscale_transform", x, lower, upper)
+
+
+def saturate(x, lower, upper):  # :333-348
+    return _affine("igx_saturate", x, lower, upper)
+
+
+def quat_diff_rad(a, b):  # :354-373
+    return _run_multi("igx_quat_diff_rad", (a, b), (4, 4), (1,), ((a.shape[0],),))[0]
+
+
+def local_to_world_space(pos_offset_local, pose_global):  # :376-395
+    return _run_multi("igx_local_to_world_space", (pos_offset_local, pose_global), (3, 7), (3,),
+                      (pos_offset_local.shape,))[0]
+
+
+def quat_to_angle_axis(q):  # :423-444
+    return _run_multi("igx_quat_to_angle_axis", (q,), (4,), (1, 3), (q.shape[:-1], q.shape[:-1] + (3,)))
+
+
+def angle_axis_to_exp_map(angle, axis):  # :446-452
+    return _run_multi("igx_angle_axis_to_exp_map", (angle.unsqueeze(-1), axis), (1, 3), (3,), (axis.shape,))[0]
+
+
+def exp_map_to_angle_axis(exp_map):  # :570-587
+    return _run_multi("igx_exp_map_to_angle_axis", (exp_map,), (3,), (1, 3), (exp_map.shape[:-1], exp_map.shape))
+
+
+def calc_heading(q):  # :630-641
+    return _run_multi("igx_calc_heading", (q,), (4,), (1,), (q.shape[:-1],))[0]
+
+
+def calc_heading_quat(q):  # :643-654
+    return _run_multi("igx_calc_heading_quat", (q,), (4,), (4,), (q.shape,))[0]
+
+
+def unscale_np(x, lower, upper):  # :244-245 (numpy on the host, as in the reference)
+    return (2.0 * x - upper - lower) / (upper - lower)
 
 
 def to_torch(x, dtype=torch.float, device="cuda:0", requires_grad=False):  # :37-38

@@ -671,6 +671,107 @@ def gen_math(seed=3, n=1536):
     print("math.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+def gen_math2(seed=4, n=1024):
+    """The rest of torch_jit_utils: every function of the module that works on [n, k] rows."""
+    _install_gym_stubs()
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    g = torch.Generator().manual_seed(seed)
+
+    def unit(q):
+        return q / q.norm(dim=-1, keepdim=True)
+
+    qa = unit(torch.randn(n, 4, generator=g))
+    qb = unit(torch.randn(n, 4, generator=g))
+    qa[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    qa[1] = torch.tensor([0.0, 0.70710678, 0.0, 0.70710678])    # pitch = +90 degrees: |sinp| >= 1 branch
+    qa[2] = torch.tensor([0.0, -0.70710678, 0.0, 0.70710678])
+    qa[3] = torch.tensor([0.0, 0.0, 0.0, -1.0])
+    v = torch.randn(n, 3, generator=g)
+    v2 = torch.randn(n, 3, generator=g)
+    v[4] = 0.0
+    out = {"qa": qa, "qb": qb, "v": v, "v2": v2}
+
+    raw4 = torch.randn(n, 4, generator=g) * 3.0
+    raw4[0] = 0.0                                               # clamp(min=1e-9) path
+    out.update(raw4=raw4, normalize3=tj.normalize(v), normalize4=tj.normalize(raw4), quat_unit=tj.quat_unit(raw4))
+    out["quat_apply"] = tj.quat_apply(qa, v)
+    qi, ti = tj.tf_inverse(qa, v)
+    out.update(tf_inverse_q=qi, tf_inverse_t=ti, tf_apply=tj.tf_apply(qa, v, v2), tf_vector=tj.tf_vector(qa, v))
+    qc, tc = tj.tf_combine(qa, v, qb, v2)
+    out.update(tf_combine_q=qc, tf_combine_t=tc, get_basis_vector=tj.get_basis_vector(qa, v))
+
+    cs_b = torch.randn(n, generator=g)
+    cs_b[:4] = torch.tensor([0.0, -0.0, float("nan"), float("inf")])
+    out.update(cs_b=cs_b, copysign_pos=tj.copysign(math.pi / 2.0, cs_b), copysign_neg=tj.copysign(-2.5, cs_b))
+
+    r, pch, y = tj.get_euler_xyz(qa)
+    out.update(euler_roll=r, euler_pitch=pch, euler_yaw=y)
+    er = (torch.rand(n, generator=g) * 2 - 1) * math.pi
+    ep = (torch.rand(n, generator=g) * 2 - 1) * math.pi
+    ey = (torch.rand(n, generator=g) * 2 - 1) * math.pi
+    er[0] = ep[0] = ey[0] = 0.0
+    out.update(er=er, ep=ep, ey=ey, quat_from_euler_xyz=tj.quat_from_euler_xyz(er, ep, ey),
+               euler_xyz_to_exp_map=tj.euler_xyz_to_exp_map(er, ep, ey))
+
+    torch.manual_seed(1234)
+    u = torch.rand(n, 6)
+    torch.manual_seed(1234)
+    out.update(rand_u=u, torch_rand_float=tj.torch_rand_float(-0.2, 0.35, (n, 6), "cpu"))
+    assert torch.equal(out["torch_rand_float"], (0.35 - -0.2) * u + -0.2)
+
+    isr = unit(torch.randn(n, 4, generator=g))
+    to_target = torch.randn(n, 3, generator=g) * 10.0
+    to_target[:, 2] = 0.0
+    to_target[5] = 0.0
+    vec0 = torch.randn(n, 3, generator=g)
+    vec1 = torch.randn(n, 3, generator=g)
+    for idx in (2, 1):
+        tq, upp, hp, upv, hv = tj.compute_heading_and_up(qa, isr, to_target, vec0, vec1, idx)
+        out.update({"hu%d_torso_quat" % idx: tq, "hu%d_up_proj" % idx: upp, "hu%d_heading_proj" % idx: hp,
+                    "hu%d_up_vec" % idx: upv, "hu%d_heading_vec" % idx: hv})
+    out.update(isr=isr, to_target=to_target, vec0=vec0, vec1=vec1)
+    targets = torch.randn(n, 3, generator=g) * 100.0
+    vl, al, rr, pp, yy, att = tj.compute_rot(qb, v, v2, targets, to_target)
+    out.update(targets=targets, rot_vel_loc=vl, rot_angvel_loc=al, rot_roll=rr, rot_pitch=pp, rot_yaw=yy,
+               rot_angle_to_target=att)
+    for ax in range(3):
+        out["quat_axis%d" % ax] = tj.quat_axis(qa, ax)
+
+    d = 12
+    lo = -torch.rand(d, generator=g) - 0.2
+    hi = torch.rand(d, generator=g) + 0.3
+    xs = torch.randn(n, d, generator=g)
+    out.update(aff_x=xs, aff_lo=lo, aff_hi=hi, scale_transform=tj.scale_transform(xs, lo, hi),
+               unscale_transform=tj.unscale_transform(xs, lo, hi), saturate=tj.saturate(xs, lo, hi))
+
+    da = qa.clone()
+    db = qb.clone()
+    db[10:20] = da[10:20]            # identical: distance 0
+    db[20:30] = -da[20:30]           # antipodal: same rotation
+    da[30:40] = da[30:40] * 1.5      # not unit: the clamp(max=1) branch
+    out.update(diff_a=da, diff_b=db, quat_diff_rad=tj.quat_diff_rad(da, db))
+
+    pose = torch.cat([torch.randn(n, 3, generator=g), qb], dim=-1)
+    out.update(pose=pose, local_to_world_space=tj.local_to_world_space(v, pose))
+
+    qe = qa.clone()
+    qe[4] = unit(torch.tensor([1e-6, 0.0, 0.0, 1.0]))
+    ang, axs = tj.quat_to_angle_axis(qe)
+    out.update(qe=qe, q2aa_angle=ang, q2aa_axis=axs, angle_axis_to_exp_map=tj.angle_axis_to_exp_map(ang, axs))
+    e = torch.randn(n, 3, generator=g) * 1.5
+    e[0] = 0.0
+    e[1] = torch.tensor([1e-7, 0.0, 0.0])
+    e[2] = torch.tensor([4.0, 0.0, 0.0])
+    ang2, axs2 = tj.exp_map_to_angle_axis(e)
+    out.update(e=e, e2aa_angle=ang2, e2aa_axis=axs2)
+    out.update(calc_heading=tj.calc_heading(qa), calc_heading_quat=tj.calc_heading_quat(qa))
+
+    out = {k: v.numpy() for k, v in out.items()}
+    out["meta"] = _meta(task="torch_jit_utils (remaining functions)", n=n, seed=seed)
+    np.savez_compressed(os.path.join(OUT, "math2.npz"), **out)
+    print("math2.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
 # --------------------------------------------------------------------------
 def success_threshold_c(tol):
     """Largest float32 c in [0, 1] with |2*asin(c)| <= tol under torch's CPU asin
@@ -1648,7 +1749,7 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math}
+GENERATORS = {"vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

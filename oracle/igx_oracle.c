@@ -10,7 +10,7 @@
  * torch.jit functions compute on CPU.  Every ATen op rounds its result to
  * fp32, so each C expression below is one rounding per operation (compile with
  * -ffp-contract=off); fmaf() appears exactly where the ATen CPU kernel fuses
- * (cross product, vector norm).  Parity pin: tests/golden/*.npz, produced by
+ * (cross product, vector norm).  Parity pin: the .npz files of tests/golden/, produced by
  * oracle/gen_golden.py from the reference's own functions
  * (torch 2.10.0 CPU) - see tests/test_oracle_golden.py.
  *
@@ -653,6 +653,272 @@ int orc_quat_to_tan_norm(const float *q, float *o, int64_t n)
 int orc_calc_heading_quat_inv(const float *q, float *o, int64_t n)
 {
     for (int64_t i = 0; i < n; ++i) { float t[4]; calc_heading_quat_inv(q + 4 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}
+
+/* ---- the rest of utils/torch_jit_utils.py ---- */
+/* :70-77 quat_apply */
+static void quat_apply(const float a[4], const float b[3], float o[3])
+{
+    float c[3], t[3], u[3];
+    cross3(a, b, c);
+    for (int i = 0; i < 3; ++i) t[i] = c[i] * 2.0f;
+    cross3(a, t, u);
+    for (int i = 0; i < 3; ++i) o[i] = b[i] + a[3] * t[i] + u[i];
+}
+
+/* :168-172 copysign(a, b) = |a| * sign(b); torch.sign is 0 for +-0 and NaN */
+static float copysign_sign(float a, float b)
+{
+    return fabsf(a) * (float)((0.0f < b) - (b < 0.0f));
+}
+
+/* :184-187, :195 pitch of get_euler_xyz */
+static float euler_pitch(const float q[4])
+{
+    float sinp = 2.0f * (q[3] * q[1] - q[2] * q[0]);
+    float pitch = (fabsf(sinp) >= 1.0f) ? copysign_sign(1.5707964f, sinp) : asinf(sinp);
+    return remainder_2pi(pitch);
+}
+
+/* :198-212 */
+static void quat_from_euler_xyz(float roll, float pitch, float yaw, float o[4])
+{
+    float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
+    float cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
+    float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+    o[3] = cy * cr * cp + sy * sr * sp;
+    o[0] = cy * sr * cp - sy * cr * sp;
+    o[1] = cy * cr * sp + sy * sr * cp;
+    o[2] = sy * cr * cp - cy * sr * sp;
+}
+
+/* :570-587 */
+static void exp_map_to_angle_axis(const float e[3], float *angle, float axis[3])
+{
+    float n = norm3(e);
+    float a = normalize_angle(n);
+    if (a > 1e-5f) {
+        *angle = a;
+        axis[0] = e[0] / n; axis[1] = e[1] / n; axis[2] = e[2] / n;
+    } else {
+        *angle = 0.0f;
+        axis[0] = 0.0f; axis[1] = 0.0f; axis[2] = 1.0f;
+    }
+}
+
+int orc_normalize(const float *x, float *o, int64_t n, int32_t d)
+{
+    if (d != 3 && d != 4) return -1;
+    for (int64_t i = 0; i < n; ++i) {
+        if (d == 3) normalize3(x + 3 * i, o + 3 * i);
+        else { float t[4]; quat_unit(x + 4 * i, t); memcpy(o + 4 * i, t, 16); }
+    }
+    return 0;
+}
+int orc_quat_unit(const float *q, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[4]; quat_unit(q + 4 * i, t); memcpy(o + 4 * i, t, 16); }
+    return 0;
+}
+int orc_quat_apply(const float *a, const float *b, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) { float t[3]; quat_apply(a + 4 * i, b + 3 * i, t); memcpy(o + 3 * i, t, 12); }
+    return 0;
+}
+/* :131-134 */
+int orc_tf_inverse(const float *q, const float *t, float *qo, float *to, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float qi[4], r[3];
+        quat_conjugate(q + 4 * i, qi);
+        quat_apply(qi, t + 3 * i, r);
+        memcpy(qo + 4 * i, qi, 16);
+        for (int k = 0; k < 3; ++k) to[3 * i + k] = -r[k];
+    }
+    return 0;
+}
+/* :137-139 */
+int orc_tf_apply(const float *q, const float *t, const float *v, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float r[3];
+        quat_apply(q + 4 * i, v + 3 * i, r);
+        for (int k = 0; k < 3; ++k) o[3 * i + k] = r[k] + t[3 * i + k];
+    }
+    return 0;
+}
+/* :147-149 */
+int orc_tf_combine(const float *q1, const float *t1, const float *q2, const float *t2, float *qo, float *to, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float qq[4], r[3];
+        quat_mul(q1 + 4 * i, q2 + 4 * i, qq);
+        quat_apply(q1 + 4 * i, t2 + 3 * i, r);
+        memcpy(qo + 4 * i, qq, 16);
+        for (int k = 0; k < 3; ++k) to[3 * i + k] = r[k] + t1[3 * i + k];
+    }
+    return 0;
+}
+int orc_copysign(float a, const float *b, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) o[i] = copysign_sign(a, b[i]);
+    return 0;
+}
+/* :175-195 */
+int orc_get_euler_xyz(const float *q, float *roll, float *pitch, float *yaw, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        euler_roll_yaw(q + 4 * i, roll + i, yaw + i);
+        pitch[i] = euler_pitch(q + 4 * i);
+    }
+    return 0;
+}
+int orc_quat_from_euler_xyz(const float *roll, const float *pitch, const float *yaw, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) quat_from_euler_xyz(roll[i], pitch[i], yaw[i], o + 4 * i);
+    return 0;
+}
+/* :563-568 */
+int orc_euler_xyz_to_exp_map(const float *roll, const float *pitch, const float *yaw, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float q[4];
+        quat_from_euler_xyz(roll[i], pitch[i], yaw[i], q);
+        quat_to_exp_map(q, o + 3 * i);
+    }
+    return 0;
+}
+/* :215-218; (upper - lower) is a Python float subtraction, the rest fp32 tensor arithmetic */
+int orc_torch_rand_float(double lower, double upper, const float *u, uint64_t seed, uint64_t off, float *o, int64_t count)
+{
+    const float span = (float)(upper - lower), lo = (float)lower;
+    for (int64_t i = 0; i < count; ++i) {
+        float r = u ? u[i] : orc_philox_uniform(seed, off, i >> 2, (int)(i & 3));
+        o[i] = span * r + lo;
+    }
+    return 0;
+}
+/* :248-263 */
+int orc_compute_heading_and_up(const float *rot, const float *isr, const float *to_target, const float *vec0,
+                               const float *vec1, int32_t up_idx, float *tq, float *up_proj, float *heading_proj,
+                               float *up_vec, float *heading_vec, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float dirs[3], q[4], up[3], hd[3];
+        normalize3(to_target + 3 * i, dirs);
+        quat_mul(rot + 4 * i, isr + 4 * i, q);
+        quat_rotate_s(q, vec1 + 3 * i, up, 0);
+        quat_rotate_s(q, vec0 + 3 * i, hd, 0);
+        memcpy(tq + 4 * i, q, 16);
+        up_proj[i] = up[up_idx];
+        heading_proj[i] = dot3(hd, dirs);
+        memcpy(up_vec + 3 * i, up, 12);
+        memcpy(heading_vec + 3 * i, hd, 12);
+    }
+    return 0;
+}
+/* :266-277 */
+int orc_compute_rot(const float *tq, const float *vel, const float *ang, const float *targets, const float *pos,
+                    float *vel_loc, float *angvel_loc, float *roll, float *pitch, float *yaw, float *angle_to_target,
+                    int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float a[3], b[3];
+        quat_rotate_s(tq + 4 * i, vel + 3 * i, a, 1);
+        quat_rotate_s(tq + 4 * i, ang + 3 * i, b, 1);
+        memcpy(vel_loc + 3 * i, a, 12);
+        memcpy(angvel_loc + 3 * i, b, 12);
+        euler_roll_yaw(tq + 4 * i, roll + i, yaw + i);
+        pitch[i] = euler_pitch(tq + 4 * i);
+        angle_to_target[i] = atan2f(targets[3 * i + 2] - pos[3 * i + 2], targets[3 * i] - pos[3 * i]) - yaw[i];
+    }
+    return 0;
+}
+/* :280-285 */
+int orc_quat_axis(const float *q, int32_t axis, float *o, int64_t n)
+{
+    float basis[3] = { 0.0f, 0.0f, 0.0f };
+    basis[axis] = 1.0f;
+    for (int64_t i = 0; i < n; ++i) { float t[3]; quat_rotate_s(q + 4 * i, basis, t, 0); memcpy(o + 3 * i, t, 12); }
+    return 0;
+}
+/* :292-310 */
+int orc_scale_transform(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
+{
+    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); float off = (lo[c] + hi[c]) * 0.5f; o[i] = 2.0f * (x[i] - off) / (hi[c] - lo[c]); }
+    return 0;
+}
+/* :313-331 */
+int orc_unscale_transform(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
+{
+    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); float off = (lo[c] + hi[c]) * 0.5f; o[i] = x[i] * (hi[c] - lo[c]) * 0.5f + off; }
+    return 0;
+}
+/* :333-348 */
+int orc_saturate(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
+{
+    return orc_tensor_clamp(x, lo, hi, o, n, d);
+}
+/* :354-373 */
+int orc_quat_diff_rad(const float *a, const float *b, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float bc[4], m[4];
+        quat_conjugate(b + 4 * i, bc);
+        quat_mul(a + 4 * i, bc, m);
+        float nrm = norm3(m);
+        o[i] = 2.0f * asinf(nrm > 1.0f ? 1.0f : nrm);
+    }
+    return 0;
+}
+/* :376-395 */
+int orc_local_to_world_space(const float *local, const float *pose, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float *ps = pose + 7 * i;
+        float ql[4] = { local[3 * i], local[3 * i + 1], local[3 * i + 2], 0.0f };
+        float qc[4], t[4], r[4];
+        quat_conjugate(ps + 3, qc);
+        quat_mul(ql, qc, t);
+        quat_mul(ps + 3, t, r);
+        for (int k = 0; k < 3; ++k) o[3 * i + k] = r[k] + ps[k];
+    }
+    return 0;
+}
+int orc_quat_to_angle_axis(const float *q, float *angle, float *axis, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) quat_to_angle_axis(q + 4 * i, angle + i, axis + 3 * i);
+    return 0;
+}
+/* :446-452 */
+int orc_angle_axis_to_exp_map(const float *angle, const float *axis, float *o, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) o[3 * i + k] = angle[i] * axis[3 * i + k];
+    return 0;
+}
+int orc_exp_map_to_angle_axis(const float *e, float *angle, float *axis, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) exp_map_to_angle_axis(e + 3 * i, angle + i, axis + 3 * i);
+    return 0;
+}
+/* :630-641 */
+int orc_calc_heading(const float *q, float *o, int64_t n)
+{
+    const float ref[3] = { 1.0f, 0.0f, 0.0f };
+    for (int64_t i = 0; i < n; ++i) { float d[3]; quat_rotate_s(q + 4 * i, ref, d, 0); o[i] = atan2f(d[1], d[0]); }
+    return 0;
+}
+/* :643-654 */
+int orc_calc_heading_quat(const float *q, float *o, int64_t n)
+{
+    const float ref[3] = { 1.0f, 0.0f, 0.0f }, zax[3] = { 0.0f, 0.0f, 1.0f };
+    for (int64_t i = 0; i < n; ++i) {
+        float d[3], t[4];
+        quat_rotate_s(q + 4 * i, ref, d, 0);
+        quat_from_angle_axis(atan2f(d[1], d[0]), zax, t);
+        memcpy(o + 4 * i, t, 16);
+    }
     return 0;
 }
 

@@ -206,6 +206,37 @@ def rowwise(name, *inputs):
     return out
 
 
+def arrays(name, inputs, out_widths, before=(), between=()):
+    """orc_<name>(*before, inputs..., *between, outputs..., n): float32 arrays in, a tuple of
+    [n, w] (or [n] for w == 1) arrays out."""
+    ins = [_f32(a) for a in inputs]
+    n = ins[0].shape[0]
+    outs = [np.empty((n, w) if w > 1 else (n,), np.float32) for w in out_widths]
+    fn = getattr(lib(), "orc_" + name)
+    args = (list(before) + [C.c_void_p(a.ctypes.data) for a in ins] + list(between) +
+            [C.c_void_p(o.ctypes.data) for o in outs] + [C.c_int64(n)])
+    assert fn(*args) == 0
+    return tuple(outs)
+
+
+def normalize(x):
+    x = _f32(x)
+    out = np.empty_like(x)
+    assert lib().orc_normalize(C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int64(x.shape[0]),
+                               C.c_int32(x.shape[1])) == 0
+    return out
+
+
+def torch_rand_float(lower, upper, uniforms, seed=0, rng_offset=0, count=None):
+    u = None if uniforms is None else _f32(uniforms)
+    count = u.size if u is not None else count
+    out = np.empty(count, np.float32)
+    assert lib().orc_torch_rand_float(C.c_double(lower), C.c_double(upper), None if u is None else C.c_void_p(u.ctypes.data),
+                                      C.c_uint64(seed), C.c_uint64(rng_offset), C.c_void_p(out.ctypes.data),
+                                      C.c_int64(count)) == 0
+    return out if u is None else out.reshape(u.shape)
+
+
 def affine(name, x, lower, upper):
     """scale / unscale / tensor_clamp of x [n, d] against lower / upper [d]."""
     x, lower, upper = _f32(x), _f32(lower), _f32(upper)

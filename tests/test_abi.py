@@ -115,6 +115,14 @@ def test_every_entry_point_rejects_null_structs():
     stage = _abi.ActionStage(mode=_abi.IGX_ACT_FIRST_DOF, num_actions=2, num_dof=2, clip_actions=1.0, actions=16, targets=16)
     assert lib.igx_action_stage_step(ctypes.byref(stage), 4, None) == _abi.IGX_E_PARAM
     assert lib.igx_quat_mul(None, None, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_quat_apply(None, None, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_tf_combine(None, None, None, None, None, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_compute_rot(*([None] * 11), 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_compute_heading_and_up(*([None] * 5), 3, *([None] * 5), 4, None) == _abi.IGX_E_PARAM
+    assert lib.igx_quat_axis(None, 5, None, 4, None) == _abi.IGX_E_PARAM
+    assert lib.igx_normalize(None, None, 4, 5, None) == _abi.IGX_E_PARAM
+    assert lib.igx_torch_rand_float(0.0, 1.0, None, 0, 0, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_get_euler_xyz(None, None, None, None, 0, None) == 0
     # empty batches are valid no-ops even with NULL pointers
     assert lib.igx_clamp(None, -1.0, 1.0, None, 0, None) == 0
     p = _abi.AmpParams(num_amp_obs_steps=1)

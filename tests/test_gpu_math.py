@@ -7,7 +7,7 @@ import torch
 from isaacgym_amd.utils import torch_jit_utils as tj
 from oracle import oracle
 from tests import helpers as H
-from tests.math_cases import AFFINE, ROWWISE
+from tests.math_cases import AFFINE, MULTI, ROWWISE, check_outputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -80,3 +80,63 @@ def test_shapes_follow_the_reference():
     assert tj.quat_mul(q, q).shape == (5, 15, 4)
     assert tj.quat_to_exp_map(q).shape == (5, 15, 3)
     assert tj.quat_to_tan_norm(q[:, 0]).shape == (5, 6)
+
+
+@pytest.mark.parametrize("case", MULTI, ids=[c[0] for c in MULTI])
+def test_remaining_functions_golden(case):
+    cid, fn, args, outk, classes, scale = case
+    g = H.load_golden("math2")
+    got = getattr(tj, fn)(*[_dev(g[a]) if isinstance(a, str) else a for a in args])
+    got = tuple(t.cpu().numpy() for t in (got if isinstance(got, tuple) else (got,)))
+    check_outputs(H, got, g, outk, classes, scale, cid)
+
+
+@pytest.mark.parametrize("n", [0, 1, 255, 257, 100003])
+def test_remaining_functions_vs_oracle_sizes(n):
+    """Sizes around the 256-row tile, an empty batch and a large odd one, against the CPU checker."""
+    from tests.test_oracle_math import OracleTJ
+    gen = torch.Generator(device=DEV).manual_seed(n + 11)
+
+    def unit(q):
+        return q / q.norm(dim=-1, keepdim=True).clamp(min=1e-9)
+
+    qa, qb = unit(torch.randn(n, 4, generator=gen, device=DEV)), unit(torch.randn(n, 4, generator=gen, device=DEV))
+    v, w, x = (torch.randn(n, 3, generator=gen, device=DEV) for _ in range(3))
+    pose = torch.cat([x, qb], dim=-1)
+    cases = [("quat_apply", (qa, v), ("exact",)), ("tf_inverse", (qa, v), ("exact", "exact")),
+             ("tf_combine", (qa, v, qb, w), ("exact", "exact")), ("tf_apply", (qa, v, w), ("exact",)),
+             ("compute_heading_and_up", (qa, qb, v, w, x, 2), ("exact",) * 5),
+             ("compute_rot", (qa, v, w, x, v), ("exact", "exact", "angle", "angle", "angle", "angle")),
+             ("local_to_world_space", (v, pose), ("exact",)), ("quat_axis", (qa, 1), ("exact",)),
+             ("normalize", (v,), ("exact",)), ("get_euler_xyz", (qa,), ("angle",) * 3),
+             ("quat_diff_rad", (qa, qb), ("tol",)), ("calc_heading_quat", (qa,), ("tol",))]
+    for name, args, classes in cases:
+        got = getattr(tj, name)(*args)
+        got = tuple(t.cpu().numpy() for t in (got if isinstance(got, tuple) else (got,)))
+        if n == 0:
+            assert all(t.shape[0] == 0 for t in got), name
+            continue
+        ref = getattr(OracleTJ, name)(*[a.cpu().numpy() if torch.is_tensor(a) else a for a in args])
+        ref = ref if isinstance(ref, tuple) else (ref,)
+        for k, (a, b, cls) in enumerate(zip(got, ref, classes)):
+            b = b.reshape(a.shape)
+            if cls == "exact":
+                assert H.bit_equal_fraction(a, b) == 1.0, (name, k)
+            elif cls == "angle":
+                H.assert_angle_close(a, b, what=name)
+            else:
+                H.assert_close(a, b, scale=np.pi, what=name)
+
+
+def test_torch_rand_float():
+    g = H.load_golden("math2")
+    u = _dev(g["rand_u"])
+    got = tj.torch_rand_float(-0.2, 0.35, tuple(u.shape), DEV, uniforms=u)
+    assert H.bit_equal_fraction(got.cpu().numpy(), g["torch_rand_float"]) == 1.0
+    # without recorded draws: the library's own counter-based stream, the same one the CPU checker restates
+    got = tj.torch_rand_float(-1.0, 3.0, (1001, 7), DEV, seed=77, rng_offset=5)
+    ref = oracle.torch_rand_float(-1.0, 3.0, None, seed=77, rng_offset=5, count=1001 * 7)
+    assert np.array_equal(got.cpu().numpy().ravel().view(np.uint32), ref.view(np.uint32))
+    assert float(got.min()) >= -1.0 and float(got.max()) < 3.0 and abs(float(got.mean()) - 1.0) < 0.1
+    other = tj.torch_rand_float(-1.0, 3.0, (1001, 7), DEV, seed=77, rng_offset=6)
+    assert not torch.equal(got, other)
