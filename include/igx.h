@@ -62,6 +62,9 @@ typedef struct igx_cartpole_params {
     int32_t reserved;
     uint64_t seed;                /* in-kernel Philox key when rand == NULL */
     uint64_t rng_offset;          /* step counter mixed into the Philox counter */
+    const uint64_t *rng_offset_dev; /* optional device-resident counter added to rng_offset when the kernel draws:
+                                     a recorded HIP graph replays the same argument values, the counter (advanced
+                                     on the stream between replays) gives every replay fresh draws; NULL = 0 */
 } igx_cartpole_params;
 
 typedef struct igx_cartpole_buffers {
@@ -115,6 +118,7 @@ typedef struct igx_loco_params {
     int32_t reserved;
     uint64_t seed;
     uint64_t rng_offset;
+    const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
 } igx_loco_params;
 
 typedef struct igx_loco_buffers {
@@ -240,6 +244,7 @@ typedef struct igx_humanoid_imitate_params {
     float dof_limits_upper[IGX_HIM_DOF + 1];
     uint64_t seed;
     uint64_t rng_offset;
+    const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
 } igx_humanoid_imitate_params;
 
 typedef struct igx_humanoid_imitate_buffers {
@@ -304,6 +309,7 @@ typedef struct igx_allegro_params {
     float dof_lower[IGX_ALLEGRO_DOF], dof_upper[IGX_ALLEGRO_DOF];
     float clip_obs;               /* env.clipObservations (+inf copies); read only with obs_clamped / states_clamped */
     uint64_t seed, rng_offset;
+    const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
 } igx_allegro_params;
 
 /* scratch for the cross-environment reduction: 16-byte records - the total, then one per tile of
@@ -400,6 +406,7 @@ typedef struct igx_shadow_params {
     int32_t fingertip_handles[IGX_SHADOW_FINGERTIPS]; /* body indices in [0, num_bodies) */
     float clip_obs;                    /* as in igx_allegro_params */
     uint64_t seed, rng_offset;
+    const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
 } igx_shadow_params;
 
 typedef struct igx_shadow_buffers {
@@ -571,6 +578,7 @@ typedef struct igx_noise {
     int32_t distribution;  /* IGX_NOISE_GAUSSIAN / IGX_NOISE_UNIFORM; read only when fresh == NULL */
     uint64_t seed;
     uint64_t offset;       /* advance by one per call */
+    const uint64_t *offset_dev; /* optional device-resident counter added to offset (for replayed graphs); NULL = 0 */
 } igx_noise;
 
 /* out = noise_lambda(x) on count floats; out may alias x. */

@@ -44,7 +44,7 @@ class _Struct(C.Structure):
 class CartpoleParams(_Struct):
     _fields_ = [("reset_dist", f32), ("max_episode_length_m1", f32),
                 ("reward_variant", i32), ("reserved", i32),
-                ("seed", u64), ("rng_offset", u64)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
 
 
 class CartpoleBuffers(_Struct):
@@ -67,7 +67,7 @@ class LocoParams(_Struct):
                 ("dof_limits_upper", f32 * IGX_MAX_DOF),
                 ("motor_efforts", f32 * IGX_MAX_DOF),
                 ("max_motor_effort", f32), ("clip_obs", f32), ("reserved", i32),
-                ("seed", u64), ("rng_offset", u64)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
 
 
 class LocoBuffers(_Struct):
@@ -100,7 +100,7 @@ class AllegroParams(_Struct):
                 ("dof_speed_scale_dt", f32),
                 ("goal_displacement", f32 * 3),
                 ("dof_lower", f32 * IGX_ALLEGRO_DOF), ("dof_upper", f32 * IGX_ALLEGRO_DOF),
-                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64)]
+                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
 
 
 class AllegroBuffers(_Struct):
@@ -134,7 +134,7 @@ class ShadowParams(_Struct):
                 ("goal_displacement", f32 * 3), ("num_bodies", i32),
                 ("dof_lower", f32 * IGX_SHADOW_DOF), ("dof_upper", f32 * IGX_SHADOW_DOF),
                 ("actuated_dof_indices", i32 * IGX_SHADOW_ACTIONS), ("fingertip_handles", i32 * IGX_SHADOW_FINGERTIPS),
-                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64)]
+                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
 
 
 class ShadowBuffers(_Struct):
@@ -187,7 +187,7 @@ IGX_ACT_FORCE, IGX_ACT_PD_TARGET, IGX_ACT_FIRST_DOF = 0, 1, 2
 class Noise(_Struct):
     _fields_ = [("corr", ptr), ("fresh", ptr),
                 ("corr_scale", f32), ("corr_shift", f32), ("scale", f32), ("shift", f32),
-                ("operation", i32), ("distribution", i32), ("seed", u64), ("offset", u64)]
+                ("operation", i32), ("distribution", i32), ("seed", u64), ("offset", u64), ("offset_dev", ptr)]
 
 
 class ActionStage(_Struct):
@@ -212,7 +212,7 @@ class HumanoidImitateParams(_Struct):
                 ("termination_height", f32), ("termination_radius_sq", f32), ("max_episode_length_m1", f32),
                 ("reserved", i32), ("targets", f32 * 3), ("clip_obs", f32),
                 ("dof_limits_lower", f32 * (IGX_HIM_DOF + 1)), ("dof_limits_upper", f32 * (IGX_HIM_DOF + 1)),
-                ("seed", u64), ("rng_offset", u64)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
 
 
 class HumanoidImitateBuffers(_Struct):

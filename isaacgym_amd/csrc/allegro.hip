@@ -49,7 +49,7 @@ __device__ __forceinline__ float allegro_draw(const igx_allegro_params &p, const
         u = b.rand[e * IGX_ALLEGRO_RAND_PER_ENV + j];
     } else {
         float q[4];
-        philox_uniform4(p.seed, p.rng_offset, e, j >> 2, q);
+        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, j >> 2, q);
         const int a = j & 3;
         u = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
     }
@@ -85,30 +85,32 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
     }
     wave_sync();
 
-    // ---- resets (rare): goal-only resets first, then full environment resets,
-    // in the order the reference applies them
-    uint64_t goal_mask = __ballot(live && rg != 0);
-    uint64_t env_mask = __ballot(live && rst != 0);
-    if (lane == 0) {
-        uint64_t m = goal_mask;
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t ee = base + src;
-            reset_target_pose(p, b, ee, allegro_draw(p, b, ee, 0), allegro_draw(p, b, ee, 1));
-        }
+    // ---- resets: goal-only resets first, then full environment resets, in the order the
+    // reference applies them.  The per-environment part (goal pose, object actor) is done by
+    // the environment's own lane, so a tile in which every environment resets (the first step:
+    // reset_buf starts at ones) costs the same as a tile with one reset.
+    if (live && rg != 0) reset_target_pose(p, b, e, allegro_draw(p, b, e, 0), allegro_draw(p, b, e, 1));
+    if (live && rst != 0) {  // target pose again (inside reset_idx), then the object actor
+        reset_target_pose(p, b, e, allegro_draw(p, b, e, 41), allegro_draw(p, b, e, 42));
+        reset_object_row(p, b, e, allegro_draw(p, b, e, 4), allegro_draw(p, b, e, 5), allegro_draw(p, b, e, 6),
+                         allegro_draw(p, b, e, 7), allegro_draw(p, b, e, 8));
     }
+    // hand joints: four flagged environments per round, lane = (slot, joint)
+    uint64_t env_mask = __ballot(live && rst != 0);
     while (env_mask) {
-        const int src = __builtin_ctzll(env_mask);
-        env_mask &= env_mask - 1;
-        const int64_t ee = base + src;
-        if (lane == 0) {  // target pose again (inside reset_idx), then the object actor
-            reset_target_pose(p, b, ee, allegro_draw(p, b, ee, 41), allegro_draw(p, b, ee, 42));
-            reset_object_row(p, b, ee, allegro_draw(p, b, ee, 4), allegro_draw(p, b, ee, 5), allegro_draw(p, b, ee, 6),
-                             allegro_draw(p, b, ee, 7), allegro_draw(p, b, ee, 8));
+        int srcs[WAVE / AD];
+#pragma unroll
+        for (int s = 0; s < WAVE / AD; ++s) {
+            srcs[s] = env_mask ? __builtin_ctzll(env_mask) : -1;
+            env_mask &= env_mask - 1;  // 0 stays 0
         }
-        if (lane < AD) {  // hand joints: lane j = joint j
-            const int j = lane;
+        const int slot = lane / AD;
+        int src = srcs[0];
+#pragma unroll
+        for (int s = 1; s < WAVE / AD; ++s) src = slot == s ? srcs[s] : src;
+        if (src >= 0) {
+            const int64_t ee = base + src;
+            const int j = lane % AD;
             const float rp = allegro_draw(p, b, ee, 4 + 5 + j);
             const float rv = allegro_draw(p, b, ee, 4 + 5 + AD + j);
             const float delta_max = s_lim[AD + j] - 0.0f, delta_min = s_lim[j] - 0.0f;

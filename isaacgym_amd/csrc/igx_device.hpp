@@ -271,6 +271,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
+// Step counter of the Philox stream: the by-value offset plus an optional device-resident
+// counter.  A recorded graph replays the same argument values; the counter, advanced on the
+// stream between replays, gives every replay fresh draws.
+__device__ __forceinline__ uint64_t rng_offset_of(uint64_t offset, const uint64_t *dev) { return dev ? offset + *dev : offset; }
+
 // Uniforms 4*blk .. 4*blk+3 of environment `env` at step `offset`, in [0,1).
 __device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t offset, int64_t env, int blk, float (&u)[4])
 {

@@ -61,7 +61,7 @@ __device__ __forceinline__ float shadow_draw(const igx_shadow_params &p, const i
         u = b.rand[e * IGX_SHADOW_RAND_PER_ENV + j];
     } else {
         float q[4];
-        philox_uniform4(p.seed, p.rng_offset, e, j >> 2, q);
+        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, j >> 2, q);
         const int a = j & 3;
         u = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
     }
@@ -109,28 +109,25 @@ __global__ __launch_bounds__(WAVE) void shadow_pre_kernel(const igx_shadow_param
     // ---- resets (rare): goal-only resets first, then full environment resets, in the order
     // the reference applies them.  Draws of an environment: 0..3 reset_target_pose from
     // pre_physics_step, 4..56 the 53 floats of reset_idx, 57..60 its inner reset_target_pose.
-    uint64_t goal_mask = __ballot(live && rg != 0);
-    uint64_t env_mask = __ballot(live && rst != 0);
-    if (lane == 0) {
-        uint64_t m = goal_mask;
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t ee = base + src;
-            reset_target_pose(p, b, ee, shadow_draw(p, b, ee, 0), shadow_draw(p, b, ee, 1));
-        }
+    // The per-environment part (goal pose, object actor) is done by the environment's own lane:
+    // a tile in which every environment resets costs the same as a tile with one reset.
+    if (live && rg != 0) reset_target_pose(p, b, e, shadow_draw(p, b, e, 0), shadow_draw(p, b, e, 1));
+    if (live && rst != 0) {
+        reset_target_pose(p, b, e, shadow_draw(p, b, e, 57), shadow_draw(p, b, e, 58));
+        reset_object_row(p, b, e, shadow_draw(p, b, e, 4), shadow_draw(p, b, e, 5), shadow_draw(p, b, e, 6),
+                         shadow_draw(p, b, e, 7), shadow_draw(p, b, e, 8));
     }
+    // hand joints (:646-655): two flagged environments per round, lane = (slot, joint)
+    uint64_t env_mask = __ballot(live && rst != 0);
     while (env_mask) {
-        const int src = __builtin_ctzll(env_mask);
+        const int src0 = __builtin_ctzll(env_mask);
         env_mask &= env_mask - 1;
-        const int64_t ee = base + src;
-        if (lane == 0) {
-            reset_target_pose(p, b, ee, shadow_draw(p, b, ee, 57), shadow_draw(p, b, ee, 58));
-            reset_object_row(p, b, ee, shadow_draw(p, b, ee, 4), shadow_draw(p, b, ee, 5), shadow_draw(p, b, ee, 6),
-                             shadow_draw(p, b, ee, 7), shadow_draw(p, b, ee, 8));
-        }
-        if (lane < SD) {  // hand joints: lane j = joint j (:646-655)
-            const int j = lane;
+        const int src1 = env_mask ? __builtin_ctzll(env_mask) : -1;
+        env_mask &= env_mask - 1;  // 0 stays 0
+        const int src = lane < SD ? src0 : (lane < 2 * SD ? src1 : -1);
+        if (src >= 0) {
+            const int64_t ee = base + src;
+            const int j = lane < SD ? lane : lane - SD;
             const float rp = shadow_draw(p, b, ee, 4 + 5 + j);
             const float rv = shadow_draw(p, b, ee, 4 + 5 + SD + j);
             const float delta_max = s_lim[SD + j] - 0.0f, delta_min = s_lim[j] - 0.0f;

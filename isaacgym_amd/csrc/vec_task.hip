@@ -46,7 +46,7 @@ __device__ __forceinline__ void store4(float *__restrict__ p, int64_t i0, int64_
 __device__ __forceinline__ void noise_draw4(const igx_noise &nz, int64_t quad, float (&f)[4])
 {
     float u[4];
-    philox_uniform4(nz.seed, nz.offset, quad, 255, u);
+    philox_uniform4(nz.seed, rng_offset_of(nz.offset, nz.offset_dev), quad, 255, u);
     if (nz.distribution == IGX_NOISE_UNIFORM) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) f[k] = u[k];

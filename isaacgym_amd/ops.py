@@ -171,6 +171,7 @@ class NoiseSpec:
         self.corr_scale, self.corr_shift, self.scale, self.shift = corr_scale, corr_shift, scale, shift
         self.operation, self.distribution = operation, distribution
         self.seed, self.offset = int(seed), 0
+        self.offset_dev = None  # address of a device-resident counter added to offset (replayed graphs)
 
     def struct(self, count, fresh=None):
         if self.corr.numel() != count or (fresh is not None and fresh.numel() != count):
@@ -180,7 +181,7 @@ class NoiseSpec:
                         corr_scale=self.corr_scale, corr_shift=self.corr_shift, scale=self.scale, shift=self.shift,
                         operation=_abi.IGX_NOISE_SCALING if self.operation == "scaling" else _abi.IGX_NOISE_ADDITIVE,
                         distribution=_abi.IGX_NOISE_UNIFORM if self.distribution == "uniform" else _abi.IGX_NOISE_GAUSSIAN,
-                        seed=self.seed, offset=self.offset)
+                        seed=self.seed, offset=self.offset, offset_dev=self.offset_dev)
         if fresh is None:
             self.offset += 1
         return nz

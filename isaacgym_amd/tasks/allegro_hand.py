@@ -128,8 +128,13 @@ class AllegroHand(VecTask):
         av32 = float(torch.tensor(self.av_factor, dtype=torch.float32))
         self._one_minus_av = 1.0 - av32
 
-    def _params(self):
-        self._draws += 1
+    _PARAM_KEY = ("obs_type", "max_consecutive_successes", "ignore_z", "use_relative_control", "dist_reward_scale",
+                  "rot_reward_scale", "rot_eps", "action_penalty_scale", "success_tolerance", "reach_goal_bonus", "fall_dist",
+                  "fall_penalty", "max_episode_length", "av_factor", "vel_obs_scale", "force_torque_obs_scale",
+                  "reset_position_noise", "reset_dof_pos_noise", "reset_dof_vel_noise", "act_moving_average",
+                  "shadow_hand_dof_speed_scale", "dt", "seed")
+
+    def _build_params(self):
         ama = float(self.act_moving_average)
         return _abi.AllegroParams(
             obs_type=_abi.ALLEGRO_OBS_TYPES[self.obs_type], max_consecutive_successes=self.max_consecutive_successes,
@@ -145,7 +150,7 @@ class AllegroHand(VecTask):
             act_moving_average=ama, one_minus_act_moving_average=1.0 - ama,
             dof_speed_scale_dt=self.shadow_hand_dof_speed_scale * self.dt,
             goal_displacement=[-0.2, -0.06, 0.12], dof_lower=self.sim.asset["dof_limits_lower"],
-            dof_upper=self.sim.asset["dof_limits_upper"], seed=self.seed, rng_offset=self._draws)
+            dof_upper=self.sim.asset["dof_limits_upper"], seed=self.seed)
 
     def _buffers(self):
         return dict(dof_state=self.dof_state, dof_force=self.dof_force_tensor,

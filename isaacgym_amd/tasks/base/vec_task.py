@@ -19,6 +19,8 @@ reference's task objects keeps working.  What differs:
   inside the kernels (Philox), not by torch.randn_like.
 """
 import numpy as np
+import ctypes as C
+
 import torch
 
 from ... import ops, randomization
@@ -137,6 +139,32 @@ class VecTask:
         return self._states_out.to(self.rl_device)
 
     # ---- to be provided by the task -------------------------------------------
+    # ---- parameter structs ----------------------------------------------------------
+    _PARAM_KEY = ()  # names of the attributes _build_params() reads
+
+    def _build_params(self):
+        raise NotImplementedError
+
+    def _params(self):
+        """This step's parameter struct.  Filling a ctypes struct with array members costs tens of
+        microseconds, so the filled struct is kept and copied until one of the attributes it was
+        built from changes (the reference reads them every step: changing one still takes effect)."""
+        self._draws += 1
+        key = tuple([getattr(self, k) for k in self._PARAM_KEY])
+        if key != getattr(self, "_ptmpl_key", None):
+            self._ptmpl, self._ptmpl_key = self._build_params(), key
+        p = type(self._ptmpl)()
+        C.memmove(C.byref(p), C.byref(self._ptmpl), C.sizeof(p))
+        p.rng_offset = self._draws
+        p.rng_offset_dev = self._rng_dev()
+        return p
+
+    def _rng_dev(self):
+        """Address of the device-resident draw counter, or None.  isaacgym_amd.graph.GraphedStep installs the
+        counter: a replayed graph repeats the by-value rng_offset, the counter keeps the draws fresh."""
+        counter = getattr(self, "_rng_counter", None)
+        return None if counter is None else counter.data_ptr()
+
     def pre_physics_step(self, actions):
         raise NotImplementedError
 
@@ -183,6 +211,7 @@ class VecTask:
             spec = ops.NoiseSpec(corr, cs, csh, sc, sh, entry["operation"],
                                  entry["distribution"], seed=(self.noise_seed << 1) | (name == "actions"))
             spec.offset = self.control_steps << 1
+            spec.offset_dev = self._rng_dev()
             entry["spec"] = spec
             entry["corr"] = spec.corr
         return spec

@@ -30,10 +30,11 @@ class Cartpole(VecTask):
         self.reset_rand = None  # optional [N,4] pre-drawn uniforms replacing the in-kernel generator
         self._draws = 0
 
-    def _params(self):
-        self._draws += 1
+    _PARAM_KEY = ("reset_dist", "max_episode_length", "seed")
+
+    def _build_params(self):
         return _abi.CartpoleParams(reset_dist=self.reset_dist, max_episode_length_m1=float(self.max_episode_length - 1),
-                                   reward_variant=self.REWARD_VARIANT, seed=self.seed, rng_offset=self._draws)
+                                   reward_variant=self.REWARD_VARIANT, seed=self.seed)
 
     def _buffers(self):
         return dict(dof_state=self.dof_state, rand=self.reset_rand, obs=self.obs_buf, rew=self.rew_buf,

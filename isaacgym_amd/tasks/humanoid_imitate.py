@@ -62,14 +62,16 @@ class HumanoidImitate(VecTask):
         self._draws = 0
         self._lo, self._hi = self.dof_limits_lower.tolist(), self.dof_limits_upper.tolist()
 
-    def _params(self):
-        self._draws += 1
+    _PARAM_KEY = ("dt", "dof_vel_scale", "up_weight", "actions_cost_scale", "termination_height", "termination_radius",
+                  "max_episode_length", "seed")
+
+    def _build_params(self):
         return _abi.HumanoidImitateParams(
             dt=self.dt, dof_vel_scale=self.dof_vel_scale, up_weight=self.up_weight,
             actions_cost_scale=self.actions_cost_scale, termination_height=self.termination_height,
             termination_radius_sq=float(np.float32(self.termination_radius ** 2)),
             max_episode_length_m1=float(self.max_episode_length - 1), targets=[1000.0, 0.0, 0.0],
-            dof_limits_lower=self._lo, dof_limits_upper=self._hi, seed=self.seed, rng_offset=self._draws)
+            dof_limits_lower=self._lo, dof_limits_upper=self._hi, seed=self.seed)
 
     def _buffers(self):
         return dict(root_states=self.root_states, dof_state=self.dof_state,

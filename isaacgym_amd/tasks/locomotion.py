@@ -83,7 +83,11 @@ class LocomotionTask(VecTask):
 
     # the per-env constant tensors of the reference (targets, inv_start_rot, basis
     # vectors) are folded into the parameter block: one value for all envs
-    def _params(self):
+    _PARAM_KEY = ("dt", "dof_vel_scale", "contact_force_scale", "angular_velocity_scale", "up_weight", "heading_weight",
+                  "actions_cost_scale", "energy_cost_scale", "joints_at_limit_cost_scale", "termination_height",
+                  "death_cost", "max_episode_length", "seed")
+
+    def _build_params(self):
         if self._const is None:  # one device-to-host read, at the first call
             self._const = dict(targets=self.targets[0].tolist(), inv_start_rot=self.inv_start_rot[0].tolist(),
                                basis_vec0=self.basis_vec0[0].tolist(), basis_vec1=self.basis_vec1[0].tolist(),
@@ -91,7 +95,6 @@ class LocomotionTask(VecTask):
                                dof_limits_upper=self.dof_limits_upper.tolist())
             if self.HUMANOID:
                 self._const.update(motor_efforts=self.motor_efforts.tolist(), max_motor_effort=self.max_motor_effort)
-        self._draws += 1
         return _abi.LocoParams(
             num_dof=self.num_dof, num_sensor_floats=self.NUM_SENSOR_FLOATS, dt=self.dt,
             dof_vel_scale=self.dof_vel_scale, contact_force_scale=self.contact_force_scale,
@@ -99,7 +102,7 @@ class LocomotionTask(VecTask):
             heading_weight=self.heading_weight, actions_cost_scale=self.actions_cost_scale,
             energy_cost_scale=self.energy_cost_scale, joints_at_limit_cost_scale=self.joints_at_limit_cost_scale,
             termination_height=self.termination_height, death_cost=self.death_cost,
-            max_episode_length_m1=float(self.max_episode_length - 1), seed=self.seed, rng_offset=self._draws,
+            max_episode_length_m1=float(self.max_episode_length - 1), seed=self.seed,
             **self._const)
 
     def _buffers(self):

@@ -116,8 +116,13 @@ class ShadowHand(VecTask):
         av32 = float(torch.tensor(self.av_factor, dtype=torch.float32))
         self._one_minus_av = 1.0 - av32
 
-    def _params(self):
-        self._draws += 1
+    _PARAM_KEY = ("obs_type", "max_consecutive_successes", "ignore_z", "use_relative_control", "dist_reward_scale",
+                  "rot_reward_scale", "rot_eps", "action_penalty_scale", "success_tolerance", "reach_goal_bonus", "fall_dist",
+                  "fall_penalty", "max_episode_length", "av_factor", "vel_obs_scale", "force_torque_obs_scale",
+                  "reset_position_noise", "reset_dof_pos_noise", "reset_dof_vel_noise", "act_moving_average",
+                  "shadow_hand_dof_speed_scale", "dt", "seed")
+
+    def _build_params(self):
         ama = float(self.act_moving_average)
         asset = self.sim.asset
         return _abi.ShadowParams(
@@ -136,7 +141,7 @@ class ShadowHand(VecTask):
             goal_displacement=[-0.2, -0.06, 0.12], num_bodies=self.num_bodies,
             dof_lower=asset["dof_limits_lower"], dof_upper=asset["dof_limits_upper"],
             actuated_dof_indices=[int(j) for j in asset["actuated_dof_indices"]],
-            fingertip_handles=[int(j) for j in asset["fingertip_handles"]], seed=self.seed, rng_offset=self._draws)
+            fingertip_handles=[int(j) for j in asset["fingertip_handles"]], seed=self.seed)
 
     def _buffers(self):
         return dict(dof_state=self.dof_state, dof_force=self.dof_force_tensor if self._full else None,

@@ -95,3 +95,50 @@ def test_quantile_select_replays_from_a_graph():
         g.replay()
         torch.cuda.synchronize()
         assert float(out["q"]) == float(torch.quantile(v, 0.9))
+
+
+@pytest.mark.parametrize("name,draws_per_step", [("Cartpole", 1), ("Ant", 1), ("Humanoid", 1), ("AntImitate", 1),
+                                                  ("HumanoidImitate", 1), ("AllegroHand", 2), ("ShadowHand", 2)])
+def test_whole_task_step_replays_from_a_graph(name, draws_per_step):
+    """task.step recorded once (isaacgym_amd.graph.GraphedStep) against an eager twin: same
+    observations, rewards, flags and reset draws, bit for bit, over steps that reset environments."""
+    from isaacgym_amd import tasks
+    from isaacgym_amd.graph import GraphedStep
+    n, warm = 3000, 2
+    eager, graphed = tasks.make(name, n, DEV, seed=3), tasks.make(name, n, DEV, seed=3)
+    for t in (eager, graphed):
+        t.sim._sets = t.sim._sets[:1]  # one set of simulator tensors, rewritten in place below
+    gs = GraphedStep(graphed, warmup=warm)
+    zero = torch.zeros(n, eager.num_actions, device=DEV)
+    for _ in range(warm):
+        eager.step(zero)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    fresh = tasks.make(name, n, DEV, seed=77).sim._sets  # other plausible simulator states to rotate in
+    for i in range(1, 5):
+        for k, v in fresh[i % len(fresh)].items():
+            eager.sim._sets[0][k].copy_(v)
+            graphed.sim._sets[0][k].copy_(v)
+        actions = torch.rand(n, eager.num_actions, generator=gen, device=DEV) * 2 - 1
+        if i == 2:  # flag a third of the environments so that the in-kernel reset draws are exercised
+            for t in (eager, graphed):
+                t.reset_buf[::3] = 1
+        eager._draws = warm * draws_per_step + (i - 1)  # the offsets replay i draws with
+        want = eager.step(actions)
+        got = gs.step(actions)
+        torch.cuda.synchronize()
+        assert graphed.control_steps == eager.control_steps
+        assert torch.equal(got[0]["obs"], want[0]["obs"]), "obs, step %d" % i
+        assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), "rew / reset, step %d" % i
+        assert torch.equal(got[3]["time_outs"], want[3]["time_outs"])
+        assert torch.equal(graphed.progress_buf, eager.progress_buf)
+        for k in eager.sim.tensors:
+            a, b = eager.sim.tensors[k], graphed.sim.tensors[k]
+            if torch.is_tensor(a) and a.shape == b.shape and k != "workspace":  # scratch: contents unspecified
+                assert torch.equal(a, b), "%s, step %d" % (k, i)
+
+
+def test_graphed_step_refuses_tasks_that_need_the_host():
+    from isaacgym_amd import tasks
+    from isaacgym_amd.graph import GraphedStep
+    with pytest.raises(ValueError):
+        GraphedStep(tasks.make("HumanoidAMP", 64, DEV))

@@ -246,3 +246,28 @@ def test_non_finite_inputs_stay_local(spec_name):
     nonangle = [c for c in range(spec["num_obs"]) if c not in H.LOCO_ANGLE_COLS]
     assert np.array_equal(got[:, nonangle][fin[:, nonangle]].view(np.uint32), want[:, nonangle][fin[:, nonangle]].view(np.uint32))
     assert np.array_equal(np.isnan(dirty["rew"].cpu().numpy()), np.isnan(ref["rew"]))
+
+
+def test_device_resident_draw_counter_adds_to_rng_offset():
+    """rng_offset_dev: the kernel draws with rng_offset + *counter (what a replayed graph relies on)."""
+    n = 5000
+    spec = synthetic.ANT
+    t = synthetic.loco_state(spec, n, 21, DEV, with_rand=False)
+    t["reset"][::2] = 1
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    counter = torch.tensor([7], dtype=torch.int64, device=DEV)
+    p = synthetic.loco_params(spec, seed=99, rng_offset=5)
+    p.rng_offset_dev = counter.data_ptr()
+    ops.ant_step(p, t, n)
+    torch.cuda.synchronize()
+    oracle.ant_step(synthetic.loco_params(spec, seed=99, rng_offset=12), ref, n)
+    for k in ("dof_state", "rew", "potentials"):
+        assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k
+    nonangle = [c for c in range(60) if c not in H.LOCO_ANGLE_COLS]
+    assert H.bit_equal_fraction(t["obs"].cpu().numpy()[:, nonangle], ref["obs"][:, nonangle]) == 1.0
+    assert np.array_equal(t["reset"].cpu().numpy(), ref["reset"])
+    # and the counter matters: without it the draws are those of rng_offset alone
+    other = synthetic.loco_state(spec, n, 21, DEV, with_rand=False)
+    other["reset"][::2] = 1
+    ops.ant_step(synthetic.loco_params(spec, seed=99, rng_offset=5), other, n)
+    assert not torch.equal(other["dof_state"], t["dof_state"])

@@ -6,6 +6,7 @@ import time
 import torch
 
 from isaacgym_amd import tasks
+from isaacgym_amd.graph import GraphedStep
 
 DEV = "cuda:0"
 for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 8), ("Humanoid", 4096, 21),
@@ -25,5 +26,15 @@ for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 
     host = (time.perf_counter() - t0) / k * 1e6
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / k * 1e6
-    print("%-12s n=%8d  host %.1f us/step  wall %.1f us/step  device span %.1f us/step" %
-          (name, n, host, wall, e0.elapsed_time(e1) / k * 1e3), flush=True)
+    line = ("%-12s n=%8d  host %.1f us/step  wall %.1f us/step  device span %.1f us/step" %
+            (name, n, host, wall, e0.elapsed_time(e1) / k * 1e3))
+    # the same step recorded once into a HIP graph and replayed
+    g = GraphedStep(tasks.make(name, n, DEV))
+    for _ in range(20):
+        g.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        g.step(a)
+    torch.cuda.synchronize()
+    print(line + "  | graph replay wall %.1f us/step" % ((time.perf_counter() - t0) / k * 1e6), flush=True)
