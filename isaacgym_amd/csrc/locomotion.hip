@@ -58,21 +58,29 @@ struct LocoLayout {
     static constexpr int IT_DOF = (DOF4 + WAVE - 1) / WAVE;
 };
 
-// reset_idx for the environments of this tile whose reset flag is set, one
-// environment at a time with the wave's lanes spread over the joints: lane j
-// draws joint j's position and velocity uniforms, writes the (pos, vel) pair
-// to dof_state and the two derived observation columns to the LDS row.
+// reset_idx for the environments of this tile whose reset flag is set, with the
+// wave's lanes spread over (environment, joint) pairs: a lane draws its joint's
+// position and velocity uniforms, writes the (pos, vel) pair to dof_state and
+// the two derived observation columns to the LDS row.
 template <int D, int S, bool HUM, int T>
 __device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx_loco_buffers &b, int64_t base,
                                              int lane, uint64_t reset_mask, float *s_tile, const float *s_lim)
 {
     using L = LocoLayout<D, S, HUM, T>;
+    // SLOTS flagged environments per round, lane = (slot, joint): when every environment of the
+    // tile resets (the first step, synchronised time-outs) the tile needs T / SLOTS rounds, not T
+    constexpr int SLOTS = WAVE / D;
+    const int slot = lane / D;
     while (reset_mask) {
-        const int src = __builtin_ctzll(reset_mask);
-        reset_mask &= reset_mask - 1;
+        uint64_t m = reset_mask;
+        for (int s = 0; s < slot; ++s) m &= m - 1;  // drop the `slot` lowest flagged environments
+        const bool have = slot < SLOTS && m != 0;
+        const int src = have ? __builtin_ctzll(m) : 0;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) reset_mask &= reset_mask - 1;  // 0 stays 0
         const int64_t e = base + src;
-        if (lane < D) {
-            const int j = lane;
+        if (have) {
+            const int j = lane - slot * D;
             float up, uv;  // uniforms j (position) and D + j (velocity) of this environment
             if (b.rand) {
                 up = b.rand[e * (2 * D) + j];
