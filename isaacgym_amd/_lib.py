@@ -154,35 +154,42 @@ _BOOL_FIELDS = {"time_outs"}
 _F64_FIELDS = {"motion_times", "motion_frame"}
 
 
-def _ptr_checked(name):
-    def f(t):
-        if name in _RAW_FIELDS:
-            return tensor_ptr(t)
-        want = (torch.int64 if name in _I64_FIELDS else torch.float64 if name in _F64_FIELDS else
-                torch.bool if name in _BOOL_FIELDS else torch.float32)
-        return tensor_ptr(t, want)
-    return f
+def _wanted_dtype(name):
+    if name in _RAW_FIELDS:
+        return None
+    return (torch.int64 if name in _I64_FIELDS else torch.float64 if name in _F64_FIELDS else
+            torch.bool if name in _BOOL_FIELDS else torch.float32)
+
+
+_FIELD_SPECS = {}  # struct class -> {field name: wanted dtype (None = any)}
 
 
 def make_buffers(cls, tensors):
     """Build a *Buffers struct from name->tensor; checks device/dtype/contiguity
     and that every tensor lives on the same device."""
+    spec = _FIELD_SPECS.get(cls)
+    if spec is None:
+        spec = _FIELD_SPECS[cls] = {n: _wanted_dtype(n) for n, _ in cls._fields_}
+    b = cls()
     dev = None
     for k, t in tensors.items():
         if t is None:
             continue
+        try:
+            want = spec[k]
+        except KeyError:
+            raise KeyError("%s has no buffer named %r" % (cls.__name__, k)) from None
+        # the checks of tensor_ptr, inlined: this loop runs for every buffer of every step
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and (want is None or t.dtype is want)):
+            tensor_ptr(t, want)  # raises the matching error
         if dev is None:
             dev = t.device
         elif t.device != dev:
             raise ValueError("buffer %r is on %s, others on %s" % (k, t.device, dev))
-    names = {n for n, _ in cls._fields_}
+        setattr(b, k, t.data_ptr())
     for k in tensors:
-        if k not in names:
+        if k not in spec:
             raise KeyError("%s has no buffer named %r" % (cls.__name__, k))
-    b = cls()
-    for n in names:
-        t = tensors.get(n)
-        setattr(b, n, None if t is None else _ptr_checked(n)(t))
     return b, dev
 
 
