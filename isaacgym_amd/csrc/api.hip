@@ -43,6 +43,6 @@ int tuning_int(const char *name, int dflt)
 
 }  // namespace igx
 
-extern "C" int igx_version(void) { return 100; }
+extern "C" int igx_version(void) { return 110; }
 
 extern "C" const char *igx_last_error_string(void) { return igx::error_buffer(); }

@@ -1321,13 +1321,17 @@ def gen_motion(seed=11):
     np.savez_compressed(os.path.join(OUT, "motion.npz"), **out)
     print("motion.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
     _gen_amp_task(lib, hamp, seed)
+    # every switch the other way: root observation in the heading frame, a deeper history, other thresholds
+    _gen_amp_task(lib, hamp, seed + 7, N=64, K=3, name="amp_alt",
+                  over=dict(localRootObs=True, terminationHeight=0.62, episodeLength=150))
 
 
-def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4):
+def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None):
     """HumanoidAMP.post_physics_step / reset_idx of the reference task class on
     synthetic simulator tensors, with the reference MotionLib built above."""
     cfg = _cfg("HumanoidAMP")
     e = cfg["env"]
+    e.update(over or {})
     g = torch.Generator().manual_seed(seed + 50)
 
     class Fake(hamp.HumanoidAMP):
@@ -1439,8 +1443,8 @@ def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4):
                         termination_height=t._termination_height, max_episode_length=t.max_episode_length,
                         enable_early_termination=bool(t._enable_early_termination), reset_before_step=2,
                         np_seed=777, state_init=e["stateInit"])
-    np.savez_compressed(os.path.join(OUT, "amp.npz"), **out)
-    print("amp.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
           "terminated", int(out["terminate"].sum()), "resets", int(out["reset"].sum()))
 
 

@@ -110,9 +110,10 @@ def test_motion_state_vs_oracle(motion, n):
     H.assert_close_near_identity(host(fused), ref, scale=np.pi, rtol=2e-5, what="fused amp obs")
 
 
-def test_amp_task_golden(motion):
+@pytest.mark.parametrize("recording", ["amp", "amp_alt"])
+def test_amp_task_golden(motion, recording):
     _, _, _, tables = motion
-    g = H.load_golden("amp")
+    g = H.load_golden(recording)
 
     def motion_state(ids, times):
         out = _state_out(len(ids), frames=False)

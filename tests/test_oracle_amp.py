@@ -1,13 +1,15 @@
 """CPU checker's HumanoidAMP step / reset against the recording of the
 reference task class (tests/golden/amp.npz; motions from motion.npz)."""
 import numpy as np
+import pytest
 
 from oracle import oracle
 from tests import helpers as H
 
 
-def test_amp_task_oracle_matches_reference():
-    g = H.load_golden("amp")
+@pytest.mark.parametrize("recording", ["amp", "amp_alt"])  # amp_alt: heading-frame root observation, 3 history steps,
+def test_amp_task_oracle_matches_reference(recording):     # other termination height and episode length
+    g = H.load_golden(recording)
     tabs = H.motion_tabs_from_golden(H.load_golden("motion"))
     fns = dict(step=oracle.humanoid_amp_step,
                reset=lambda p, b, env_ids, state: oracle.humanoid_amp_reset(p, b, env_ids, state),
