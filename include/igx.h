@@ -650,7 +650,7 @@ int igx_clamp(const float *x, float lo, float hi, float *out, int64_t count, igx
  * Here a capture is a gather kernel on the producer's stream into a device
  * staging slot, and a hipMemcpyAsync into pinned host memory on the recorder's
  * own side stream, ordered by events.  A slot batches consecutive steps up to about
- * 1 MiB per copy; the producer waits only when the ring of slots is full, i.e. when
+ * 128 MiB (at most 64 steps) per copy; the producer waits only when the ring of slots is full, i.e. when
  * it produces faster than the host link drains.
  * Host layout: [max_steps][num_cols][n_rows] fp32 (step-major), pinned.
  * ---------------------------------------------------------------------- */

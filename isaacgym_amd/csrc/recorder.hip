@@ -9,8 +9,8 @@
 //                                 record(slot_free[s])
 //
 // A slot batches B consecutive steps (B slabs of [num_cols][n_rows] are contiguous on the host
-// as well), B chosen so that a copy moves about 1 MiB: small captures would otherwise be bound
-// by the per-copy latency of the copy engine, and the producer with them.  The producer only
+// as well), B chosen so that a copy moves up to 128 MiB (at most 64 steps): small copies are bound by the
+// per-copy latency of the copy engine, and the producer with them; large ones run at the link's rate.  The producer only
 // ever waits for a copy that is S batches old; igx_recorder_sync flushes a partly filled batch.  Replaces the
 // per-step obs.clone().cpu() + torch.cat of tasks/cartpole_sample.py:119-121,
 // :289-293 (reference paths relative to IsaacGymEnvs/isaacgymenvs/).
@@ -86,8 +86,12 @@ extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t r
     r->n_rows = n_rows; r->row_width = row_width; r->num_cols = num_cols; r->ring_slots = ring_slots;
     r->max_steps = max_steps;
     const int64_t slab_bytes = (int64_t)sizeof(float) * slab;
-    r->batch = ((int64_t)1 << 20) / slab_bytes;
+    // steps per host copy: copies of a hundred MiB run at the link's rate (8 MiB ones at 3/4, 1 MiB ones at
+    // 1/2 of it); at most 64 steps, so that small captures do not sit on the device for long
+    static const int64_t target = (int64_t)tuning_int("IGX_RECORDER_COPY_MIB", 128) << 20;
+    r->batch = target / slab_bytes;
     r->batch = r->batch < 1 ? 1 : r->batch > 64 ? 64 : r->batch;
+    if (r->batch > max_steps) r->batch = max_steps;
     REC_HIP(hipGetDevice(&r->device), "hipGetDevice");
     REC_HIP(hipMalloc(&r->d_cols, sizeof(int32_t) * num_cols), "hipMalloc(cols)");
     REC_HIP(hipMemcpy(r->d_cols, cols, sizeof(int32_t) * num_cols, hipMemcpyHostToDevice), "hipMemcpy(cols)");
