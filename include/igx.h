@@ -488,9 +488,31 @@ typedef struct igx_motion_state_out { /* every pointer may be NULL to skip that 
 } igx_motion_state_out;
 
 /* MotionLib.get_motion_state (tasks/amp/utils_amp/motion_lib.py:83-153) with
- * _calc_frame_blend (:233-241, fp64) and _local_rotation_to_dof (:265-293). */
+ * _calc_frame_blend (:233-241, fp64) and _local_rotation_to_dof (:265-293).
+ * A motion id outside [0, num_motions) is a hole: that sample's output rows are left untouched
+ * (here and in igx_motion_amp_obs), so that a masked list can be processed without the host. */
 int igx_motion_state(const igx_motion_tables *t, const int64_t *motion_ids, const double *motion_times,
                      int64_t n, const igx_motion_state_out *out, igx_stream_t stream);
+
+/* Reference-state sampling for resets without a round trip to the host.  The reference finds the
+ * flagged environments with nonzero() and samples on the host with numpy (tasks/humanoid_amp.py:220-246:
+ * MotionLib.sample_motions = np.random.choice(m, p=weights), tasks/amp/utils_amp/motion_lib.py:61-65;
+ * sample_time = uniform phase * motion length, :67-78).  Here, for every environment e:
+ *   reset[e] != 0: env_ids[e] = e, motion_ids[e] = first i with u0 < cdf[i], motion_times[e] = u1 * length
+ *                  (random_time != 0, stateInit Random) or 0 (stateInit Start);
+ *   otherwise:     env_ids[e] = motion_ids[e] = -1, motion_times[e] = 0 - holes that igx_motion_state,
+ *                  igx_motion_amp_obs and igx_humanoid_amp_reset skip.
+ * u0, u1 come from the library's Philox4x32-10 stream keyed by (seed, rng_offset, e): the distribution is
+ * the reference's, the stream is not numpy's. */
+typedef struct igx_motion_sampler {
+    const double *cdf;              /* [num_motions] cumulative weights / their total (device memory) */
+    int32_t random_time;
+    int32_t reserved;
+    uint64_t seed, rng_offset;
+    const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+} igx_motion_sampler;
+int igx_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset, int64_t n,
+                              int64_t *env_ids, int64_t *motion_ids, double *motion_times, igx_stream_t stream);
 
 /* build_amp_observations (tasks/humanoid_amp.py:337-371) == compute_humanoid_observations
  * (tasks/amp/humanoid_amp_base.py:542-576) with dof_to_obs (:510-540).
@@ -546,7 +568,7 @@ int igx_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int
  * then recompute obs[env_ids] and amp_obs[env_ids, 0] from the (not yet refreshed)
  * rigid_body_state, and copy it into every history slot (the _init_amp_obs_default
  * behaviour; reference-state resets overwrite the history afterwards with
- * igx_motion_amp_obs). */
+ * igx_motion_amp_obs).  A negative entry of env_ids is a hole and is skipped. */
 int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, const int64_t *env_ids, int64_t m,
                            const igx_motion_state_out *state, igx_stream_t stream);
 

@@ -161,6 +161,11 @@ class MotionTables(_Struct):
                 ("root_ang_vel", ptr), ("key_pos", ptr), ("dof_vel", ptr)]
 
 
+class MotionSampler(_Struct):
+    _fields_ = [("cdf", ptr), ("random_time", i32), ("reserved", i32), ("seed", u64), ("rng_offset", u64),
+                ("rng_offset_dev", ptr)]
+
+
 class MotionStateOut(_Struct):
     _fields_ = [("root_pos", ptr), ("root_rot", ptr), ("dof_pos", ptr), ("root_vel", ptr),
                 ("root_ang_vel", ptr), ("dof_vel", ptr), ("key_pos", ptr),

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
     const int item = (int)(gid & 15);
     if (s >= n) return;
     const int64_t id = ids[s];
+    if (id < 0 || id >= t.num_motions) return;  // not a motion: this sample's output rows are left as they are
     const FrameBlend f = calc_frame_blend(t, id, times[s]);
     float *orow = AMP_OBS ? obs + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset : nullptr;
 
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(64) void amp_reset_kernel(const igx_amp_params p, c
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const int K = p.num_amp_obs_steps;
-    if (i < m) {
-        const int64_t e = env_ids[i];
+    const int64_t e = i < m ? env_ids[i] : -1;
+    if (e >= 0) {  // negative ids are holes of a masked list (igx_motion_sample_flagged)
         float *r = b.root_states + e * 13;
         if (s.root_pos) for (int c = 0; c < 3; ++c) r[c] = s.root_pos[i * 3 + c];
         if (s.root_rot) for (int c = 0; c < 4; ++c) r[3 + c] = s.root_rot[i * 4 + c];
@@ -566,6 +567,33 @@ __global__ __launch_bounds__(64) void amp_reset_kernel(const igx_amp_params p, c
             for (int k = 0; k < K; ++k) b.amp_obs[(e * K + k) * NO + c] = v;
         }
     }
+}
+
+// MotionLib.sample_motions (motion_lib.py:61-65: np.random.choice(m, p=weights) = first index whose
+// cumulative weight exceeds a uniform draw) and sample_time (:67-78: uniform phase * motion length) for
+// the environments whose reset flag is set, with the draws of the library's own Philox stream.
+__global__ __launch_bounds__(256) void motion_sample_flagged_kernel(const igx_motion_tables t, const igx_motion_sampler s,
+                                                                    const int64_t *__restrict__ reset, int64_t n,
+                                                                    int64_t *__restrict__ env_ids,
+                                                                    int64_t *__restrict__ motion_ids,
+                                                                    double *__restrict__ motion_times)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    int64_t id = -1, env = -1;
+    double time = 0.0;
+    if (reset[e] != 0) {
+        float u[4];
+        philox_uniform4(s.seed, rng_offset_of(s.rng_offset, s.rng_offset_dev), e, 0, u);
+        const double pick = (double)u[0];
+        id = 0;
+        while (id < t.num_motions - 1 && !(pick < s.cdf[id])) ++id;
+        time = s.random_time ? (double)u[1] * t.motion_length[id] : 0.0;
+        env = e;
+    }
+    env_ids[e] = env;
+    motion_ids[e] = id;
+    motion_times[e] = time;
 }
 
 static int check_tables(const igx_motion_tables *t, const char *who)
@@ -672,4 +700,20 @@ extern "C" int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buf
     hipLaunchKernelGGL(amp_reset_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), *p,
                        *b, env_ids, m, *state);
     return launch_status("igx_humanoid_amp_reset");
+}
+
+extern "C" int igx_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset,
+                                         int64_t n, int64_t *env_ids, int64_t *motion_ids, double *motion_times,
+                                         igx_stream_t stream)
+{
+    int rc = check_tables(t, "igx_motion_sample_flagged");
+    if (rc != IGX_OK) return rc;
+    if (!s) return fail(IGX_E_NULL, "igx_motion_sample_flagged: sampler struct is NULL");
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "igx_motion_sample_flagged: n out of range");
+    if (n == 0) return IGX_OK;
+    if (!s->cdf || !reset || !env_ids || !motion_ids || !motion_times)
+        return fail(IGX_E_NULL, "igx_motion_sample_flagged: NULL argument");
+    hipLaunchKernelGGL(motion_sample_flagged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *t, *s, reset, n, env_ids, motion_ids, motion_times);
+    return launch_status("igx_motion_sample_flagged");
 }

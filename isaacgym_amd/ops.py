@@ -115,6 +115,26 @@ def motion_state(tables, motion_ids, motion_times, out):
     _lib.check(rc)
 
 
+def motion_sample_flagged(tables, cdf, reset, env_ids, motion_ids, motion_times, random_time=True, seed=0, rng_offset=0,
+                          rng_offset_dev=None):
+    """Reference-state sampling for the environments whose reset flag is set, on the device (no nonzero(),
+    no numpy): fills env_ids / motion_ids / motion_times [n]; environments without the flag get -1 / -1 / 0,
+    which motion_state, motion_amp_obs and humanoid_amp_reset skip."""
+    dev = reset.device
+    s = _abi.MotionSampler(cdf=_lib.tensor_ptr(cdf, torch.float64), random_time=int(bool(random_time)), seed=int(seed),
+                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev)
+    n = reset.shape[0]
+    for t in (env_ids, motion_ids, motion_times):
+        if t.shape[0] != n:
+            raise ValueError("outputs must have one entry per environment")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_motion_sample_flagged(C.byref(tables), C.byref(s), _lib.tensor_ptr(reset, torch.int64),
+                                                  C.c_int64(n), _lib.tensor_ptr(env_ids, torch.int64),
+                                                  _lib.tensor_ptr(motion_ids, torch.int64),
+                                                  _lib.tensor_ptr(motion_times, torch.float64), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 def motion_amp_obs(tables, motion_ids, motion_times, local_root_obs, out, out_rows=None, out_row_stride=None,
                    out_col_offset=0):
     dev = motion_ids.device

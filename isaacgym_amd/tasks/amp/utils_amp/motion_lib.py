@@ -179,6 +179,14 @@ class MotionLib:
         m = self.num_motions()
         return np.random.choice(m, size=n, replace=True, p=self._motion_weights)
 
+    def sampling_cdf(self):
+        """The cumulative weights np.random.choice searches (cumsum divided by its last entry), fp64, on the device."""
+        if getattr(self, "_cdf", None) is None:
+            cdf = self._motion_weights.cumsum()
+            cdf /= cdf[-1]
+            self._cdf = torch.from_numpy(np.ascontiguousarray(cdf, np.float64)).to(self._device)
+        return self._cdf
+
     def sample_time(self, motion_ids, truncate_time=None):  # motion_lib.py:67-78
         phase = np.random.uniform(low=0.0, high=1.0, size=motion_ids.shape)
         motion_len = self._motion_lengths[motion_ids]

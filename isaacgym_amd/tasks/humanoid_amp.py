@@ -274,6 +274,41 @@ class HumanoidAMP(HumanoidAMPBase):
         if len(default_reset_ids) > 0:
             self._reset_default(default_reset_ids.contiguous())
 
+    def reset_flagged(self, seed=0):
+        """reset_done() without the host, for stateInit Random / Start: the flagged environments are found,
+        their reference motions and times drawn (weights and uniform phase as MotionLib.sample_motions /
+        sample_time, from the library's counter-based generator instead of numpy's), the motion states
+        evaluated and written, and the AMP history filled, all by kernels that run over every environment
+        and skip the ones without the flag.  No nonzero(), no device-to-host copy, no numpy."""
+        if self._state_init not in (HumanoidAMP.StateInit.Random, HumanoidAMP.StateInit.Start):
+            raise ValueError("reset_flagged handles stateInit Random and Start; use reset_done() for %s" % self._state_init.name)
+        n, K, dev, lib = self.num_envs, self._num_amp_obs_steps, self.device, self._motion_lib
+        w = getattr(self, "_flagged_ws", None)
+        if w is None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            w = self._flagged_ws = dict(
+                env_ids=torch.empty(n, dtype=torch.int64, device=dev), ids=torch.empty(n, dtype=torch.int64, device=dev),
+                times=torch.empty(n, dtype=torch.float64, device=dev),
+                state=dict(root_pos=torch.empty(n, 3, **f32), root_rot=torch.empty(n, 4, **f32),
+                           dof_pos=torch.empty(n, 28, **f32), root_vel=torch.empty(n, 3, **f32),
+                           root_ang_vel=torch.empty(n, 3, **f32), dof_vel=torch.empty(n, 28, **f32)),
+                rows=(torch.arange(n, device=dev).unsqueeze(-1) * K + 1 + torch.arange(K - 1, device=dev)).flatten().contiguous(),
+                back=-self.dt * (torch.arange(K - 1, device=dev, dtype=torch.float64) + 1), draws=0)
+        w["draws"] += 1
+        ops.motion_sample_flagged(lib._tables, lib.sampling_cdf(), self.reset_buf, w["env_ids"], w["ids"], w["times"],
+                                  random_time=self._state_init == HumanoidAMP.StateInit.Random, seed=seed,
+                                  rng_offset=w["draws"], rng_offset_dev=self._rng_dev())
+        ops.motion_state(lib._tables, w["ids"], w["times"], w["state"])
+        ops.humanoid_amp_reset(self._params(), self._buffers(), w["env_ids"], w["state"])
+        # the history slots: the same motions at times - dt, - 2 dt, ... (humanoid_amp.py:279-294)
+        hist_ids = w["ids"].unsqueeze(-1).expand(n, K - 1).reshape(-1).contiguous()
+        hist_times = (w["times"].unsqueeze(-1) + w["back"]).reshape(-1).contiguous()
+        ops.motion_amp_obs(lib._tables, hist_ids, hist_times, self._local_root_obs, self._amp_obs_buf, out_rows=w["rows"],
+                           out_row_stride=NUM_AMP_OBS_PER_STEP)
+        self.sim.notify_root_state(self._root_states, None)
+        self.sim.notify_dof_state(None)
+        return self._publish_obs()
+
     def _set_env_state(self, env_ids, root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel):
         state = dict(root_pos=root_pos, root_rot=root_rot, dof_pos=dof_pos, root_vel=root_vel,
                      root_ang_vel=root_ang_vel, dof_vel=dof_vel)

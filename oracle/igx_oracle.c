@@ -1436,6 +1436,7 @@ int orc_motion_state(const igx_motion_tables *t, const int64_t *ids, const doubl
     for (int64_t s = 0; s < n; ++s) {
         float rp[3], rr[4], dp[28], rv[3], rav[3], dv[28], kp[12], bl;
         int64_t i0, i1;
+        if (ids[s] < 0 || ids[s] >= t->num_motions) continue; /* a hole of a masked list */
         motion_state_one(t, ids[s], times[s], rp, rr, dp, rv, rav, dv, kp, &i0, &i1, &bl);
         if (o->root_pos) memcpy(o->root_pos + s * 3, rp, 12);
         if (o->root_rot) memcpy(o->root_rot + s * 4, rr, 16);
@@ -1504,6 +1505,7 @@ int orc_motion_amp_obs(const igx_motion_tables *t, const int64_t *ids, const dou
 {
     for (int64_t s = 0; s < n; ++s) {
         float rp[3], rr[4], dp[28], rv[3], rav[3], dv[28], kp[12];
+        if (ids[s] < 0 || ids[s] >= t->num_motions) continue; /* a hole of a masked list */
         motion_state_one(t, ids[s], times[s], rp, rr, dp, rv, rav, dv, kp, NULL, NULL, NULL);
         float *o = out + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset;
         amp_obs_one(rp, rr, rv, rav, dp, 1, dv, 1, kp, local_root_obs, o);
@@ -1559,12 +1561,36 @@ int orc_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int
 }
 
 /* tasks/humanoid_amp.py:184-204, :296-310, :274-277 (see include/igx.h) */
+/* Sampling of reference states for the flagged environments with the library's Philox stream:
+ * tasks/amp/utils_amp/motion_lib.py:61-65 (np.random.choice(m, p=weights): first index whose cumulative
+ * weight exceeds the draw) and :67-78 (uniform phase * motion length). */
+int orc_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset, int64_t n,
+                              int64_t *env_ids, int64_t *motion_ids, double *motion_times)
+{
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t id = -1, env = -1;
+        double time = 0.0;
+        if (reset[e] != 0) {
+            double pick = (double)orc_philox_uniform(s->seed, s->rng_offset, e, 0);
+            id = 0;
+            while (id < t->num_motions - 1 && !(pick < s->cdf[id])) ++id;
+            time = s->random_time ? (double)orc_philox_uniform(s->seed, s->rng_offset, e, 1) * t->motion_length[id] : 0.0;
+            env = e;
+        }
+        env_ids[e] = env;
+        motion_ids[e] = id;
+        motion_times[e] = time;
+    }
+    return 0;
+}
+
 int orc_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buffers *b, const int64_t *env_ids, int64_t m,
                            const igx_motion_state_out *s)
 {
     const int K = p->num_amp_obs_steps;
     for (int64_t i = 0; i < m; ++i) {
         const int64_t e = env_ids[i];
+        if (e < 0) continue; /* a hole of a masked list */
         float *r = b->root_states + e * 13;
         if (s->root_pos) memcpy(r, s->root_pos + i * 3, 12);
         if (s->root_rot) memcpy(r + 3, s->root_rot + i * 4, 16);

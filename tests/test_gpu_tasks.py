@@ -9,6 +9,7 @@ from isaacgym_amd import ops, synthetic, tasks
 from isaacgym_amd.sim import ReplaySim, SyntheticSim, TensorSim
 from isaacgym_amd.tasks.amp.utils_amp.motion_lib import MotionLib
 from isaacgym_amd.tasks.base.vec_task import VecTask
+from oracle import oracle
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -396,3 +397,55 @@ def test_ant_with_randomization_noise():
     cols = d[:, :12]   # columns that do not depend on the actions
     assert abs(float(cols.mean())) < 1e-4 and abs(float(cols.std()) - 0.002) < 2e-4
     assert noisy.last_rand_step >= 0 and not noisy.first_randomization
+
+
+@pytest.mark.parametrize("state_init", ["Random", "Start"])
+def test_amp_reset_flagged_equals_the_host_path_on_the_same_draws(motion_lib, state_init):
+    """reset_flagged() never leaves the device.  Its draws (read back here) fed through the host path
+    of a twin task - reset_idx machinery on the list of flagged ids - must give the same tensors."""
+    n = 5000
+    a, b = (_amp_task(motion_lib, n, stateInit=state_init) for _ in range(2))
+    zero = torch.zeros(n, 28, device=DEV)
+    for t in (a, b):
+        t.reset_buf.zero_()
+        t.step(zero)
+        t.step(zero)
+        t.reset_buf[::3] = 1
+        t.reset_buf[-1] = 1
+    untouched = {k: v.clone() for k, v in (("root", a._root_states), ("dof", a._dof_state), ("amp", a._amp_obs_buf),
+                                           ("progress", a.progress_buf))}
+    flags = host(a.reset_buf).copy()
+    a.reset_flagged(seed=31)
+    w = a._flagged_ws
+    env_ids, ids, times = host(w["env_ids"]), host(w["ids"]), host(w["times"])
+    # the sampler against the CPU checker, bit for bit
+    g = H.load_golden("motion")
+    cdf = host(motion_lib.sampling_cdf())
+    want = oracle.motion_sample_flagged(H.motion_tabs_from_golden(g), cdf, flags, state_init == "Random", seed=31, rng_offset=1)
+    assert np.array_equal(env_ids, want[0]) and np.array_equal(ids, want[1])
+    assert np.array_equal(times.view(np.uint64), want[2].view(np.uint64))
+    flagged = np.nonzero(flags)[0]
+    assert np.array_equal(env_ids[flagged], flagged) and (ids[flagged] >= 0).all()
+    if state_init == "Start":
+        assert (times == 0).all()
+    # the twin: the reference's sequence on the host with these ids / times
+    fl = dev(flagged)
+    root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, _ = motion_lib.get_motion_state(ids[flagged], times[flagged])
+    b._set_env_state(env_ids=fl, root_pos=root_pos, root_rot=root_rot, dof_pos=dof_pos, root_vel=root_vel,
+                     root_ang_vel=root_ang_vel, dof_vel=dof_vel)
+    b._init_amp_obs_ref(fl, ids[flagged], times[flagged])
+    torch.cuda.synchronize()
+    for k, x, y in (("root", a._root_states, b._root_states), ("dof", a._dof_state, b._dof_state), ("obs", a.obs_buf, b.obs_buf),
+                    ("amp_obs", a._amp_obs_buf, b._amp_obs_buf), ("progress", a.progress_buf, b.progress_buf),
+                    ("reset", a.reset_buf, b.reset_buf), ("terminate", a._terminate_buf, b._terminate_buf)):
+        assert torch.equal(x, y), k
+    assert int(a.reset_buf.sum()) == 0 and int(a.progress_buf[fl].sum()) == 0
+    # environments without the flag keep every bit
+    keep = np.nonzero(flags == 0)[0]
+    for k, x in (("root", a._root_states), ("dof", a._dof_state), ("amp", a._amp_obs_buf), ("progress", a.progress_buf)):
+        assert torch.equal(x[keep], untouched[k][keep]), k
+
+
+def test_amp_reset_flagged_refuses_other_state_inits(motion_lib):
+    with pytest.raises(ValueError):
+        _amp_task(motion_lib, 64, stateInit="Hybrid").reset_flagged()

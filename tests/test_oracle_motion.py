@@ -35,3 +35,46 @@ def test_fused_motion_amp_obs_matches_reference():
     oracle.motion_amp_obs(tabs, g["ids"], g["times"], 0, buf, out_rows=rows, out_row_stride=210, out_col_offset=105)
     assert np.array_equal(buf[rows, 1], out)
     assert not buf[:, 0].any()
+
+
+def test_flagged_sampler_follows_numpy_choice_and_uniform_phase():
+    """The device-side reset sampling, restated: np.random.choice(m, p=w) is searchsorted(cumsum(w) / total,
+    u, side="right"), sample_time is u * length; holes for the environments without the flag."""
+    g = H.load_golden("motion")
+    tabs = H.motion_tabs_from_golden(g)
+    lengths = np.asarray(g["motion_lengths"], np.float64)
+    w = np.array([1.0, 3.0])
+    cdf = w.cumsum()
+    cdf /= cdf[-1]
+    n = 20000
+    reset = (np.random.default_rng(3).random(n) < 0.6).astype(np.int64)
+    env_ids, ids, times = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=4)
+    hole = reset == 0
+    assert (env_ids[hole] == -1).all() and (ids[hole] == -1).all() and (times[hole] == 0).all()
+    flagged = np.nonzero(reset)[0]
+    assert np.array_equal(env_ids[flagged], flagged)
+    u0 = np.array([oracle.philox_uniform(11, 4, int(e), 0) for e in flagged[:500]], np.float64)
+    u1 = np.array([oracle.philox_uniform(11, 4, int(e), 1) for e in flagged[:500]], np.float64)
+    assert np.array_equal(ids[flagged[:500]], np.searchsorted(cdf, u0, side="right"))
+    assert np.array_equal(times[flagged[:500]], u1 * lengths[ids[flagged[:500]]])
+    assert abs((ids[flagged] == 1).mean() - 0.75) < 0.02
+    phase = times[flagged] / lengths[ids[flagged]]
+    assert 0.0 <= phase.min() and phase.max() < 1.0 and abs(phase.mean() - 0.5) < 0.02
+    _, ids0, times0 = oracle.motion_sample_flagged(tabs, cdf, reset, False, seed=11, rng_offset=4)
+    assert np.array_equal(ids0, ids) and (times0 == 0).all()     # stateInit Start
+    _, ids2, _ = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=5)
+    assert not np.array_equal(ids2, ids)
+
+
+def test_holes_are_skipped_by_motion_state_and_reset():
+    g = H.load_golden("motion")
+    tabs = H.motion_tabs_from_golden(g)
+    ids = np.array([0, -1, 1, 7, 1], np.int64)       # -1 and 7 are not motions
+    times = np.array([0.3, 0.1, 0.2, 0.0, 0.5])
+    out = oracle.motion_state(tabs, ids, times)
+    ref = oracle.motion_state(tabs, np.array([0, 1, 1], np.int64), times[[0, 2, 4]])
+    for k in ("root_pos", "dof_pos", "root_rot"):
+        assert np.array_equal(out[k][[0, 2, 4]], ref[k]) and (out[k][[1, 3]] == 0).all(), k
+    obs = np.full((5, 105), 9.0, np.float32)
+    oracle.motion_amp_obs(tabs, ids, times, 0, obs)
+    assert (obs[[1, 3]] == 9.0).all() and (obs[[0, 2, 4]] != 9.0).any(axis=1).all()
