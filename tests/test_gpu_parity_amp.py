@@ -57,6 +57,25 @@ def test_motion_state_partial_outputs(motion):
     H.assert_close(host(out["dof_pos"]), g["dof_pos"], scale=np.pi, what="dof_pos")
 
 
+def test_ids_that_are_not_motions_are_holes(motion):
+    """A negative or too large motion id leaves its output rows alone (masked lists, and no read outside the tables)."""
+    g, _, _, tables = motion
+    ids = g["ids"].copy()
+    n = len(ids)
+    holes = np.arange(0, n, 5)
+    ids[holes[::2]] = -1
+    ids[holes[1::2]] = 1000
+    out = dict(dof_pos=torch.full((n, 28), 9.0, device=DEV), root_rot=torch.full((n, 4), 9.0, device=DEV))
+    ops.motion_state(tables, dev(ids), dev(g["times"]), out)
+    obs = torch.full((n, 105), 9.0, device=DEV)
+    ops.motion_amp_obs(tables, dev(ids), dev(g["times"]), 0, obs)
+    keep = np.setdiff1d(np.arange(n), holes)
+    assert (host(out["dof_pos"])[holes] == 9.0).all() and (host(out["root_rot"])[holes] == 9.0).all()
+    assert (host(obs)[holes] == 9.0).all()
+    H.assert_close(host(out["dof_pos"])[keep], g["dof_pos"][keep], scale=np.pi, what="dof_pos")
+    assert (host(obs)[keep] != 9.0).any(axis=1).all()
+
+
 @pytest.mark.parametrize("lro", [0, 1])
 def test_amp_observations_golden(motion, lro):
     g = motion[0]
