@@ -10,20 +10,21 @@ fresh through a device-resident counter that the graph itself advances by one pe
 that the kernels add to rng_offset (`rng_offset_dev` of the parameter structs).
 
 What a replay cannot do is run host code: tasks whose step depends on it are refused
-(domain-randomisation schedules, HumanoidAMP's numpy motion sampling, host-side printing).
+(domain-randomisation schedules, host-side printing, the trajectory recorder).  Resets that
+the reference does between steps on the host (HumanoidAMP's reset_done) can ride along as a
+`prologue` when the task has a device-only form of them (HumanoidAMP.reset_flagged).
 """
 import torch
 
 
 class GraphedStep:
-    def __init__(self, task, warmup=3):
-        """Records task.step.  `warmup` eager steps run first (code objects load, lazy tensors appear)."""
+    def __init__(self, task, warmup=3, prologue=None):
+        """Records `prologue()` (optional, e.g. task.reset_flagged) followed by task.step.  `warmup` eager
+        rounds run first (code objects load, lazy tensors appear)."""
         if getattr(task, "randomize", False):
             raise ValueError("a replayed graph cannot run the host-side domain-randomisation schedule")
         if getattr(task, "print_success_stat", False):
             raise ValueError("printNumSuccesses prints from the host every step")
-        if type(task).__name__ in ("HumanoidAMP",):
-            raise ValueError("%s samples its reset states with numpy on the host every step" % type(task).__name__)
         if getattr(task, "_recorder", None) is not None:
             raise ValueError("the trajectory recorder counts its captures on the host")
         if torch.device(task.rl_device) != torch.device(task.device):
@@ -37,6 +38,8 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
+                if prologue is not None:
+                    prologue()
                 task.step(self.actions)
         torch.cuda.current_stream(dev).wait_stream(side)
         # the graph advances the counter before the step: from -1 the first replay draws with exactly
@@ -46,6 +49,8 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             task._rng_counter.add_(1)
+            if prologue is not None:
+                prologue()
             self.outputs = task.step(self.actions)
         task.control_steps -= 1  # recording enqueued nothing: that step has not happened
 

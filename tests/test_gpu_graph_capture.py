@@ -140,5 +140,47 @@ def test_whole_task_step_replays_from_a_graph(name, draws_per_step):
 def test_graphed_step_refuses_tasks_that_need_the_host():
     from isaacgym_amd import tasks
     from isaacgym_amd.graph import GraphedStep
+    task = tasks.make("Ant", 64, DEV)
+    task.randomize = True
     with pytest.raises(ValueError):
-        GraphedStep(tasks.make("HumanoidAMP", 64, DEV))
+        GraphedStep(task)
+    with pytest.raises(ValueError):
+        GraphedStep(tasks.make("CartpoleSample", 64, DEV, sample=True))  # its recorder counts captures on the host
+
+
+def test_humanoid_amp_reset_and_step_replay_from_a_graph(tmp_path):
+    """HumanoidAMP: device-only resets (reset_flagged) + step in one recorded graph against an eager twin."""
+    from isaacgym_amd import cfg as C
+    from isaacgym_amd import tasks
+    from isaacgym_amd.graph import GraphedStep
+    from isaacgym_amd.sim import SyntheticSim
+    from isaacgym_amd.tasks.amp.utils_amp.motion_lib import MotionLib
+    from tests import helpers as H
+    lib = MotionLib(H.write_golden_motions(H.load_golden("motion"), str(tmp_path)), 28, [5, 8, 11, 14], DEV)
+    n, warm = 2000, 2
+
+    def make():
+        cfg = C.task_config("HumanoidAMP", n)
+        t = tasks.HumanoidAMP(cfg, DEV, DEV, sim=SyntheticSim("HumanoidAMP", n, DEV, seed=7, num_amp_obs_steps=2), motion_lib=lib)
+        t.sim._sets = t.sim._sets[:1]
+        return t
+
+    eager, graphed = make(), make()
+    gs = GraphedStep(graphed, warmup=warm, prologue=graphed.reset_flagged)
+    zero = torch.zeros(n, 28, device=DEV)
+    for _ in range(warm):
+        eager.reset_flagged()
+        eager.step(zero)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    for i in range(1, 4):
+        actions = torch.rand(n, 28, generator=gen, device=DEV) * 2 - 1
+        if i == 2:
+            for t in (eager, graphed):
+                t.reset_buf[::4] = 1
+        eager.reset_flagged()
+        want = eager.step(actions)
+        got = gs.step(actions)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0]["obs"], want[0]["obs"]) and torch.equal(got[2], want[2]), i
+        assert torch.equal(graphed._amp_obs_buf, eager._amp_obs_buf), i
+        assert torch.equal(graphed._dof_state, eager._dof_state) and torch.equal(graphed.progress_buf, eager.progress_buf), i
