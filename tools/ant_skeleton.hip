@@ -97,6 +97,46 @@ __global__ __launch_bounds__(TPB) void skel_split(Bufs b, int64_t ntiles)
     if (lane < 48) { ST((v4f *)(b.up + base * 3) + lane, r[3]); ST((v4f *)(b.head + base * 3) + lane, r[7]); }
 }
 
+// one-shot, 64-thread blocks, the sixteen 16-byte loads issued by inline assembly with a given
+// cache-policy suffix (POL: 0 nt, 1 sc1 nt, 2 sc0 sc1 nt, 3 sc1, 4 sc0 sc1, 5 none); stores nt
+#define LOAD_POL(dst, ptr, pol) asm volatile("global_load_dwordx4 %0, %1, off " pol : "=v"(dst) : "v"(ptr) : "memory")
+template <int POL>
+__global__ __launch_bounds__(64) void skel_pol(Bufs b, int64_t ntiles)
+{
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t base = tile * 64;
+    v4f r[16];
+    const v4f *p[16];
+    const v4f *g = (const v4f *)(b.root + base * 13);
+    p[0] = g + lane; p[1] = g + 64 + lane; p[2] = g + 128 + lane; p[3] = g + 192 + (lane & 15);
+    g = (const v4f *)(b.dof + base * 16);
+    for (int i = 0; i < 4; ++i) p[4 + i] = g + 64 * i + lane;
+    g = (const v4f *)(b.sens + base * 24);
+    for (int i = 0; i < 6; ++i) p[8 + i] = g + 64 * i + lane;
+    g = (const v4f *)(b.act + base * 8);
+    p[14] = g + lane; p[15] = g + 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (POL == 0) LOAD_POL(r[i], p[i], "nt");
+        else if (POL == 1) LOAD_POL(r[i], p[i], "sc1 nt");
+        else if (POL == 2) LOAD_POL(r[i], p[i], "sc0 sc1 nt");
+        else if (POL == 3) LOAD_POL(r[i], p[i], "sc1");
+        else if (POL == 4) LOAD_POL(r[i], p[i], "sc0 sc1");
+        else LOAD_POL(r[i], p[i], "");
+    }
+    float pot = b.pot[base + lane]; int64_t rs = b.reset[base + lane], pg = b.prog[base + lane], rn = b.rnd[base + lane];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                 "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
+    v4f *og = (v4f *)(b.obs + base * 60);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) __builtin_nontemporal_store(r[i] + r[15], og + 64 * i + lane);
+    b.pot[base + lane] = pot + 1.0f; b.prev[base + lane] = pot; b.rew[base + lane] = pot * 2.0f;
+    b.reset[base + lane] = rs ^ 1; b.prog[base + lane] = pg + 1; b.rnd[base + lane] = rn + 1;
+    if (lane < 48) { __builtin_nontemporal_store(r[3], (v4f *)(b.up + base * 3) + lane); __builtin_nontemporal_store(r[7], (v4f *)(b.head + base * 3) + lane); }
+}
+
 template <class F>
 static double time_ms(F f, int iters)
 {
@@ -154,6 +194,9 @@ int main(int argc, char **argv)
     RUNS(64, true, (unsigned)ntiles, "split_w64_nt");
     RUNS(256, true, (unsigned)(ntiles / 4), "split_b256_nt");
     RUNS(256, false, (unsigned)(ntiles / 4), "split_b256");
+#define RUNP(POL, NAME) emit(NAME, time_ms([&](int i) { hipLaunchKernelGGL((skel_pol<POL>), dim3((unsigned)ntiles), dim3(64), 0, 0, s[i % NS], ntiles); }, 30))
+    RUNP(0, "loads_nt"); RUNP(1, "loads_sc1_nt"); RUNP(2, "loads_sc0_sc1_nt"); RUNP(3, "loads_sc1"); RUNP(4, "loads_sc0_sc1"); RUNP(5, "loads_default");
+    RUNP(0, "loads_nt_again");
     RUN(64, true, false, 2048, "persist_w64_g2048");
     RUN(64, true, false, 4096, "persist_w64_g4096");
     RUN(64, true, false, 8192, "persist_w64_g8192");
