@@ -498,21 +498,26 @@ int igx_motion_state(const igx_motion_tables *t, const int64_t *motion_ids, cons
  * flagged environments with nonzero() and samples on the host with numpy (tasks/humanoid_amp.py:220-246:
  * MotionLib.sample_motions = np.random.choice(m, p=weights), tasks/amp/utils_amp/motion_lib.py:61-65;
  * sample_time = uniform phase * motion length, :67-78).  Here, for every environment e:
- *   reset[e] != 0: env_ids[e] = e, motion_ids[e] = first i with u0 < cdf[i], motion_times[e] = u1 * length
- *                  (random_time != 0, stateInit Random) or 0 (stateInit Start);
- *   otherwise:     env_ids[e] = motion_ids[e] = -1, motion_times[e] = 0 - holes that igx_motion_state,
- *                  igx_motion_amp_obs and igx_humanoid_amp_reset skip.
- * u0, u1 come from the library's Philox4x32-10 stream keyed by (seed, rng_offset, e): the distribution is
- * the reference's, the stream is not numpy's. */
+ *   reset[e] != 0 and u2 < ref_init_prob (a reference-state reset, :220-246):
+ *                  env_ids[e] = e, motion_ids[e] = first i with u0 < cdf[i], motion_times[e] = u1 * length
+ *                  (random_time != 0, stateInit Random / Hybrid) or 0 (stateInit Start);
+ *   reset[e] != 0 otherwise (a default-pose reset, :206-218; stateInit Default is ref_init_prob = 0,
+ *                  Hybrid is hybridInitProb, :248-261): default_env_ids[e] = e;
+ *   everything else is a hole: env_ids / motion_ids / default_env_ids = -1, motion_times = 0, which
+ *                  igx_motion_state, igx_motion_amp_obs and igx_humanoid_amp_reset skip.
+ * u0, u1, u2 come from the library's Philox4x32-10 stream keyed by (seed, rng_offset, e): the distributions
+ * are the reference's, the stream is not numpy's / torch's.  default_env_ids may be NULL when
+ * ref_init_prob >= 1. */
 typedef struct igx_motion_sampler {
     const double *cdf;              /* [num_motions] cumulative weights / their total (device memory) */
     int32_t random_time;
-    int32_t reserved;
+    float ref_init_prob;            /* 1: every reset takes a reference state */
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
 } igx_motion_sampler;
 int igx_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset, int64_t n,
-                              int64_t *env_ids, int64_t *motion_ids, double *motion_times, igx_stream_t stream);
+                              int64_t *env_ids, int64_t *motion_ids, double *motion_times, int64_t *default_env_ids,
+                              igx_stream_t stream);
 
 /* build_amp_observations (tasks/humanoid_amp.py:337-371) == compute_humanoid_observations
  * (tasks/amp/humanoid_amp_base.py:542-576) with dof_to_obs (:510-540).

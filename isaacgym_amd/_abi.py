@@ -162,7 +162,7 @@ class MotionTables(_Struct):
 
 
 class MotionSampler(_Struct):
-    _fields_ = [("cdf", ptr), ("random_time", i32), ("reserved", i32), ("seed", u64), ("rng_offset", u64),
+    _fields_ = [("cdf", ptr), ("random_time", i32), ("ref_init_prob", f32), ("seed", u64), ("rng_offset", u64),
                 ("rng_offset_dev", ptr)]
 
 

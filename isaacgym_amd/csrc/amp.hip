@@ -576,24 +576,30 @@ __global__ __launch_bounds__(256) void motion_sample_flagged_kernel(const igx_mo
                                                                     const int64_t *__restrict__ reset, int64_t n,
                                                                     int64_t *__restrict__ env_ids,
                                                                     int64_t *__restrict__ motion_ids,
-                                                                    double *__restrict__ motion_times)
+                                                                    double *__restrict__ motion_times,
+                                                                    int64_t *__restrict__ default_env_ids)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    int64_t id = -1, env = -1;
+    int64_t id = -1, env = -1, denv = -1;
     double time = 0.0;
     if (reset[e] != 0) {
         float u[4];
         philox_uniform4(s.seed, rng_offset_of(s.rng_offset, s.rng_offset_dev), e, 0, u);
-        const double pick = (double)u[0];
-        id = 0;
-        while (id < t.num_motions - 1 && !(pick < s.cdf[id])) ++id;
-        time = s.random_time ? (double)u[1] * t.motion_length[id] : 0.0;
-        env = e;
+        if (u[2] < s.ref_init_prob) {
+            const double pick = (double)u[0];
+            id = 0;
+            while (id < t.num_motions - 1 && !(pick < s.cdf[id])) ++id;
+            time = s.random_time ? (double)u[1] * t.motion_length[id] : 0.0;
+            env = e;
+        } else {
+            denv = e;
+        }
     }
     env_ids[e] = env;
     motion_ids[e] = id;
     motion_times[e] = time;
+    if (default_env_ids) default_env_ids[e] = denv;
 }
 
 static int check_tables(const igx_motion_tables *t, const char *who)
@@ -704,7 +710,7 @@ extern "C" int igx_humanoid_amp_reset(const igx_amp_params *p, const igx_amp_buf
 
 extern "C" int igx_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset,
                                          int64_t n, int64_t *env_ids, int64_t *motion_ids, double *motion_times,
-                                         igx_stream_t stream)
+                                         int64_t *default_env_ids, igx_stream_t stream)
 {
     int rc = check_tables(t, "igx_motion_sample_flagged");
     if (rc != IGX_OK) return rc;
@@ -713,7 +719,10 @@ extern "C" int igx_motion_sample_flagged(const igx_motion_tables *t, const igx_m
     if (n == 0) return IGX_OK;
     if (!s->cdf || !reset || !env_ids || !motion_ids || !motion_times)
         return fail(IGX_E_NULL, "igx_motion_sample_flagged: NULL argument");
+    if (!(s->ref_init_prob >= 0.0f)) return fail(IGX_E_PARAM, "igx_motion_sample_flagged: ref_init_prob must be >= 0");
+    if (s->ref_init_prob < 1.0f && !default_env_ids)
+        return fail(IGX_E_NULL, "igx_motion_sample_flagged: default_env_ids is NULL with ref_init_prob < 1");
     hipLaunchKernelGGL(motion_sample_flagged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), *t, *s, reset, n, env_ids, motion_ids, motion_times);
+                       static_cast<hipStream_t>(stream), *t, *s, reset, n, env_ids, motion_ids, motion_times, default_env_ids);
     return launch_status("igx_motion_sample_flagged");
 }

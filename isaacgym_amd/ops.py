@@ -116,22 +116,25 @@ def motion_state(tables, motion_ids, motion_times, out):
 
 
 def motion_sample_flagged(tables, cdf, reset, env_ids, motion_ids, motion_times, random_time=True, seed=0, rng_offset=0,
-                          rng_offset_dev=None):
+                          rng_offset_dev=None, ref_init_prob=1.0, default_env_ids=None):
     """Reference-state sampling for the environments whose reset flag is set, on the device (no nonzero(),
     no numpy): fills env_ids / motion_ids / motion_times [n]; environments without the flag get -1 / -1 / 0,
-    which motion_state, motion_amp_obs and humanoid_amp_reset skip."""
+    which motion_state, motion_amp_obs and humanoid_amp_reset skip.  With ref_init_prob < 1 a flagged
+    environment takes the default pose with probability 1 - ref_init_prob: it is listed in default_env_ids
+    instead (stateInit Hybrid; 0 = stateInit Default)."""
     dev = reset.device
     s = _abi.MotionSampler(cdf=_lib.tensor_ptr(cdf, torch.float64), random_time=int(bool(random_time)), seed=int(seed),
-                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev)
+                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev, ref_init_prob=float(ref_init_prob))
     n = reset.shape[0]
-    for t in (env_ids, motion_ids, motion_times):
+    for t in (env_ids, motion_ids, motion_times) + ((default_env_ids,) if default_env_ids is not None else ()):
         if t.shape[0] != n:
             raise ValueError("outputs must have one entry per environment")
     with torch.cuda.device(dev):
         rc = _lib.lib().igx_motion_sample_flagged(C.byref(tables), C.byref(s), _lib.tensor_ptr(reset, torch.int64),
                                                   C.c_int64(n), _lib.tensor_ptr(env_ids, torch.int64),
                                                   _lib.tensor_ptr(motion_ids, torch.int64),
-                                                  _lib.tensor_ptr(motion_times, torch.float64), _lib.current_stream(dev))
+                                                  _lib.tensor_ptr(motion_times, torch.float64),
+                                                  _lib.tensor_ptr(default_env_ids, torch.int64), _lib.current_stream(dev))
     _lib.check(rc)
 
 

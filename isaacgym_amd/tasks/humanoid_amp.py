@@ -275,19 +275,21 @@ class HumanoidAMP(HumanoidAMPBase):
             self._reset_default(default_reset_ids.contiguous())
 
     def reset_flagged(self, seed=0):
-        """reset_done() without the host, for stateInit Random / Start: the flagged environments are found,
-        their reference motions and times drawn (weights and uniform phase as MotionLib.sample_motions /
-        sample_time, from the library's counter-based generator instead of numpy's), the motion states
-        evaluated and written, and the AMP history filled, all by kernels that run over every environment
-        and skip the ones without the flag.  No nonzero(), no device-to-host copy, no numpy."""
-        if self._state_init not in (HumanoidAMP.StateInit.Random, HumanoidAMP.StateInit.Start):
-            raise ValueError("reset_flagged handles stateInit Random and Start; use reset_done() for %s" % self._state_init.name)
+        """reset_done() without the host: the flagged environments are found, the choice between reference
+        state and default pose made (stateInit Hybrid), reference motions and times drawn (weights and uniform
+        phase as MotionLib.sample_motions / sample_time; the library's counter-based generator stands where
+        numpy's and torch.bernoulli stand), the motion states evaluated and written, and the AMP history
+        filled, all by kernels that run over every environment and skip the ones without the flag.
+        No nonzero(), no device-to-host copy, no numpy."""
+        SI = HumanoidAMP.StateInit
+        ref_prob = {SI.Default: 0.0, SI.Start: 1.0, SI.Random: 1.0, SI.Hybrid: float(self._hybrid_init_prob)}[self._state_init]
         n, K, dev, lib = self.num_envs, self._num_amp_obs_steps, self.device, self._motion_lib
         w = getattr(self, "_flagged_ws", None)
         if w is None:
             f32 = dict(dtype=torch.float32, device=dev)
             w = self._flagged_ws = dict(
                 env_ids=torch.empty(n, dtype=torch.int64, device=dev), ids=torch.empty(n, dtype=torch.int64, device=dev),
+                default_ids=torch.empty(n, dtype=torch.int64, device=dev),
                 times=torch.empty(n, dtype=torch.float64, device=dev),
                 state=dict(root_pos=torch.empty(n, 3, **f32), root_rot=torch.empty(n, 4, **f32),
                            dof_pos=torch.empty(n, 28, **f32), root_vel=torch.empty(n, 3, **f32),
@@ -296,8 +298,15 @@ class HumanoidAMP(HumanoidAMPBase):
                 back=-self.dt * (torch.arange(K - 1, device=dev, dtype=torch.float64) + 1), draws=0)
         w["draws"] += 1
         ops.motion_sample_flagged(lib._tables, lib.sampling_cdf(), self.reset_buf, w["env_ids"], w["ids"], w["times"],
-                                  random_time=self._state_init == HumanoidAMP.StateInit.Random, seed=seed,
-                                  rng_offset=w["draws"], rng_offset_dev=self._rng_dev())
+                                  random_time=self._state_init in (SI.Random, SI.Hybrid), seed=seed,
+                                  rng_offset=w["draws"], rng_offset_dev=self._rng_dev(), ref_init_prob=ref_prob,
+                                  default_env_ids=w["default_ids"])
+        if ref_prob < 1.0:  # default pose: joints from the initial state, the root row stays (humanoid_amp_base.py:392-408)
+            ops.humanoid_amp_reset(self._params(), self._buffers(), w["default_ids"],
+                                   dict(dof_pos=self._initial_dof_pos, dof_vel=self._initial_dof_vel))
+        if ref_prob <= 0.0:
+            self.sim.notify_dof_state(None)
+            return self._publish_obs()
         ops.motion_state(lib._tables, w["ids"], w["times"], w["state"])
         ops.humanoid_amp_reset(self._params(), self._buffers(), w["env_ids"], w["state"])
         # the history slots: the same motions at times - dt, - 2 dt, ... (humanoid_amp.py:279-294)

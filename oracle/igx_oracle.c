@@ -1565,12 +1565,14 @@ int orc_humanoid_amp_step(const igx_amp_params *p, const igx_amp_buffers *b, int
  * tasks/amp/utils_amp/motion_lib.py:61-65 (np.random.choice(m, p=weights): first index whose cumulative
  * weight exceeds the draw) and :67-78 (uniform phase * motion length). */
 int orc_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset, int64_t n,
-                              int64_t *env_ids, int64_t *motion_ids, double *motion_times)
+                              int64_t *env_ids, int64_t *motion_ids, double *motion_times, int64_t *default_env_ids)
 {
     for (int64_t e = 0; e < n; ++e) {
-        int64_t id = -1, env = -1;
+        int64_t id = -1, env = -1, denv = -1;
         double time = 0.0;
-        if (reset[e] != 0) {
+        if (reset[e] != 0 && !(orc_philox_uniform(s->seed, s->rng_offset, e, 2) < s->ref_init_prob)) {
+            denv = e; /* tasks/humanoid_amp.py:248-261: this one takes the default pose */
+        } else if (reset[e] != 0) {
             double pick = (double)orc_philox_uniform(s->seed, s->rng_offset, e, 0);
             id = 0;
             while (id < t->num_motions - 1 && !(pick < s->cdf[id])) ++id;
@@ -1580,6 +1582,7 @@ int orc_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampl
         env_ids[e] = env;
         motion_ids[e] = id;
         motion_times[e] = time;
+        if (default_env_ids) default_env_ids[e] = denv;
     }
     return 0;
 }

@@ -172,18 +172,20 @@ def motion_amp_obs(tabs, ids, times, local_root_obs, out, out_rows=None, out_row
                                     C.c_int64(out_row_stride), C.c_int64(out_col_offset)) == 0
 
 
-def motion_sample_flagged(tabs, cdf, reset, random_time, seed, rng_offset):
-    """Returns (env_ids, motion_ids, motion_times), each [n]; holes are -1 / -1 / 0."""
+def motion_sample_flagged(tabs, cdf, reset, random_time, seed, rng_offset, ref_init_prob=1.0):
+    """Returns (env_ids, motion_ids, motion_times, default_env_ids), each [n]; holes are -1 / -1 / 0 / -1."""
     reset = np.ascontiguousarray(reset, np.int64)
     cdf = np.ascontiguousarray(cdf, np.float64)
     n = len(reset)
     env_ids, ids, times = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float64)
+    default_ids = np.zeros(n, np.int64)
     t = motion_tables(tabs)
-    s = _abi.MotionSampler(cdf=cdf.ctypes.data, random_time=int(random_time), seed=seed, rng_offset=rng_offset)
+    s = _abi.MotionSampler(cdf=cdf.ctypes.data, random_time=int(random_time), ref_init_prob=ref_init_prob, seed=seed,
+                           rng_offset=rng_offset)
     assert lib().orc_motion_sample_flagged(C.byref(t), C.byref(s), C.c_void_p(reset.ctypes.data), C.c_int64(n),
                                            C.c_void_p(env_ids.ctypes.data), C.c_void_p(ids.ctypes.data),
-                                           C.c_void_p(times.ctypes.data)) == 0
-    return env_ids, ids, times
+                                           C.c_void_p(times.ctypes.data), C.c_void_p(default_ids.ctypes.data)) == 0
+    return env_ids, ids, times, default_ids
 
 
 def humanoid_amp_step(params, bufs, n):

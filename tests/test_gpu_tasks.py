@@ -399,7 +399,7 @@ def test_ant_with_randomization_noise():
     assert noisy.last_rand_step >= 0 and not noisy.first_randomization
 
 
-@pytest.mark.parametrize("state_init", ["Random", "Start"])
+@pytest.mark.parametrize("state_init", ["Random", "Start", "Hybrid", "Default"])
 def test_amp_reset_flagged_equals_the_host_path_on_the_same_draws(motion_lib, state_init):
     """reset_flagged() never leaves the device.  Its draws (read back here) fed through the host path
     of a twin task - reset_idx machinery on the list of flagged ids - must give the same tensors."""
@@ -417,23 +417,32 @@ def test_amp_reset_flagged_equals_the_host_path_on_the_same_draws(motion_lib, st
     flags = host(a.reset_buf).copy()
     a.reset_flagged(seed=31)
     w = a._flagged_ws
-    env_ids, ids, times = host(w["env_ids"]), host(w["ids"]), host(w["times"])
+    env_ids, ids, times, dflt = host(w["env_ids"]), host(w["ids"]), host(w["times"]), host(w["default_ids"])
+    prob = dict(Random=1.0, Start=1.0, Hybrid=float(a._hybrid_init_prob), Default=0.0)[state_init]
     # the sampler against the CPU checker, bit for bit
     g = H.load_golden("motion")
     cdf = host(motion_lib.sampling_cdf())
-    want = oracle.motion_sample_flagged(H.motion_tabs_from_golden(g), cdf, flags, state_init == "Random", seed=31, rng_offset=1)
-    assert np.array_equal(env_ids, want[0]) and np.array_equal(ids, want[1])
+    want = oracle.motion_sample_flagged(H.motion_tabs_from_golden(g), cdf, flags, state_init in ("Random", "Hybrid"), seed=31,
+                                        rng_offset=1, ref_init_prob=prob)
+    assert np.array_equal(env_ids, want[0]) and np.array_equal(ids, want[1]) and np.array_equal(dflt, want[3])
     assert np.array_equal(times.view(np.uint64), want[2].view(np.uint64))
     flagged = np.nonzero(flags)[0]
-    assert np.array_equal(env_ids[flagged], flagged) and (ids[flagged] >= 0).all()
+    ref_ids, def_ids = np.nonzero(env_ids >= 0)[0], np.nonzero(dflt >= 0)[0]
+    assert np.array_equal(np.sort(np.concatenate([ref_ids, def_ids])), flagged) and (ids[ref_ids] >= 0).all()
+    if state_init == "Hybrid":
+        assert 0 < len(ref_ids) < len(flagged)
     if state_init == "Start":
         assert (times == 0).all()
     # the twin: the reference's sequence on the host with these ids / times
     fl = dev(flagged)
-    root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, _ = motion_lib.get_motion_state(ids[flagged], times[flagged])
-    b._set_env_state(env_ids=fl, root_pos=root_pos, root_rot=root_rot, dof_pos=dof_pos, root_vel=root_vel,
-                     root_ang_vel=root_ang_vel, dof_vel=dof_vel)
-    b._init_amp_obs_ref(fl, ids[flagged], times[flagged])
+    if len(ref_ids):
+        rf = dev(ref_ids)
+        root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, _ = motion_lib.get_motion_state(ids[ref_ids], times[ref_ids])
+        b._set_env_state(env_ids=rf, root_pos=root_pos, root_rot=root_rot, dof_pos=dof_pos, root_vel=root_vel,
+                         root_ang_vel=root_ang_vel, dof_vel=dof_vel)
+        b._init_amp_obs_ref(rf, ids[ref_ids], times[ref_ids])
+    if len(def_ids):
+        b._reset_default(dev(def_ids))
     torch.cuda.synchronize()
     for k, x, y in (("root", a._root_states, b._root_states), ("dof", a._dof_state, b._dof_state), ("obs", a.obs_buf, b.obs_buf),
                     ("amp_obs", a._amp_obs_buf, b._amp_obs_buf), ("progress", a.progress_buf, b.progress_buf),
@@ -446,6 +455,3 @@ def test_amp_reset_flagged_equals_the_host_path_on_the_same_draws(motion_lib, st
         assert torch.equal(x[keep], untouched[k][keep]), k
 
 
-def test_amp_reset_flagged_refuses_other_state_inits(motion_lib):
-    with pytest.raises(ValueError):
-        _amp_task(motion_lib, 64, stateInit="Hybrid").reset_flagged()

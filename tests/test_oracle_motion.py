@@ -48,7 +48,8 @@ def test_flagged_sampler_follows_numpy_choice_and_uniform_phase():
     cdf /= cdf[-1]
     n = 20000
     reset = (np.random.default_rng(3).random(n) < 0.6).astype(np.int64)
-    env_ids, ids, times = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=4)
+    env_ids, ids, times, dflt = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=4)
+    assert (dflt == -1).all()
     hole = reset == 0
     assert (env_ids[hole] == -1).all() and (ids[hole] == -1).all() and (times[hole] == 0).all()
     flagged = np.nonzero(reset)[0]
@@ -60,10 +61,19 @@ def test_flagged_sampler_follows_numpy_choice_and_uniform_phase():
     assert abs((ids[flagged] == 1).mean() - 0.75) < 0.02
     phase = times[flagged] / lengths[ids[flagged]]
     assert 0.0 <= phase.min() and phase.max() < 1.0 and abs(phase.mean() - 0.5) < 0.02
-    _, ids0, times0 = oracle.motion_sample_flagged(tabs, cdf, reset, False, seed=11, rng_offset=4)
+    _, ids0, times0, _ = oracle.motion_sample_flagged(tabs, cdf, reset, False, seed=11, rng_offset=4)
     assert np.array_equal(ids0, ids) and (times0 == 0).all()     # stateInit Start
-    _, ids2, _ = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=5)
+    _, ids2, _, _ = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=5)
     assert not np.array_equal(ids2, ids)
+    # stateInit Hybrid: a flagged environment takes a reference state with probability p, else the default pose
+    env_h, ids_h, times_h, dflt_h = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=4, ref_init_prob=0.3)
+    ref_h, def_h = env_h >= 0, dflt_h >= 0
+    assert not (ref_h & def_h).any() and np.array_equal(ref_h | def_h, reset != 0)
+    assert abs(ref_h.sum() / max(1, (reset != 0).sum()) - 0.3) < 0.02
+    assert np.array_equal(ids_h[ref_h], ids[ref_h]) and np.array_equal(times_h[ref_h], times[ref_h])   # same draws
+    assert (ids_h[~ref_h] == -1).all() and np.array_equal(dflt_h[def_h], np.nonzero(def_h)[0])
+    env_d, ids_d, _, dflt_d = oracle.motion_sample_flagged(tabs, cdf, reset, True, seed=11, rng_offset=4, ref_init_prob=0.0)
+    assert (env_d == -1).all() and (ids_d == -1).all() and np.array_equal(dflt_d >= 0, reset != 0)  # stateInit Default
 
 
 def test_holes_are_skipped_by_motion_state_and_reset():
