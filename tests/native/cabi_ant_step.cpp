@@ -112,31 +112,68 @@ int main(int argc, char **argv)
     h.true_objective = h_tobj.data(); h.obs_clamped = h_obsc.data(); h.time_outs = h_tout.data();
     if (orc_ant_step(&p, &h, n) != 0) return 1;
 
-    std::vector<float> g_obs, g_rew, g_pot, g_obsc, g_dof;
-    std::vector<int64_t> g_reset, g_prog, g_rnd;
-    std::vector<uint8_t> g_tout;
-    if (obs.down(g_obs) || rew.down(g_rew) || pot.down(g_pot) || obsc.down(g_obsc) || dof.down(g_dof) || reset.down(g_reset) ||
-        prog.down(g_prog) || rnd.down(g_rnd) || tout.down(g_tout))
-        return 2;
-    int64_t bad = 0;
-    for (int64_t e = 0; e < n; ++e) {
-        bad += g_reset[e] != reset.host[e] || g_prog[e] != prog.host[e] || g_rnd[e] != rnd.host[e] || g_tout[e] != h_tout[e];
-        bad += std::memcmp(&g_rew[e], &h_rew[e], 4) != 0 || std::memcmp(&g_pot[e], &pot.host[e], 4) != 0;
-        for (int c = 0; c < NOBS; ++c) {
-            const float a = g_obs[e * NOBS + c], w = h_obs[e * NOBS + c];
-            if (c >= 7 && c <= 9) {  // yaw, roll, angle to target: atan2 of the device math library, 1e-5 of pi
-                float diff = std::fabs(a - w);
-                diff = std::fmin(diff, std::fabs(diff - 6.2831855f));
-                bad += !(diff <= 1e-5f * 3.1415927f);
-            } else {
-                bad += std::memcmp(&a, &w, 4) != 0;
+    // device buffers against the checker's host arrays
+    auto mismatches = [&](int64_t &bad) -> int {
+        std::vector<float> g_obs, g_rew, g_pot, g_obsc, g_dof;
+        std::vector<int64_t> g_reset, g_prog, g_rnd;
+        std::vector<uint8_t> g_tout;
+        if (obs.down(g_obs) || rew.down(g_rew) || pot.down(g_pot) || obsc.down(g_obsc) || dof.down(g_dof) || reset.down(g_reset) ||
+            prog.down(g_prog) || rnd.down(g_rnd) || tout.down(g_tout))
+            return 2;
+        bad = 0;
+        for (int64_t e = 0; e < n; ++e) {
+            bad += g_reset[e] != reset.host[e] || g_prog[e] != prog.host[e] || g_rnd[e] != rnd.host[e] || g_tout[e] != h_tout[e];
+            bad += std::memcmp(&g_rew[e], &h_rew[e], 4) != 0 || std::memcmp(&g_pot[e], &pot.host[e], 4) != 0;
+            for (int c = 0; c < NOBS; ++c) {
+                const float a = g_obs[e * NOBS + c], w = h_obs[e * NOBS + c];
+                if (c >= 7 && c <= 9) {  // yaw, roll, angle to target: atan2 of the device math library, 1e-5 of pi
+                    float diff = std::fabs(a - w);
+                    diff = std::fmin(diff, std::fabs(diff - 6.2831855f));
+                    bad += !(diff <= 1e-5f * 3.1415927f);
+                } else {
+                    bad += std::memcmp(&a, &w, 4) != 0;
+                }
+                const float cl = std::fmin(std::fmax(a, -p.clip_obs), p.clip_obs);
+                bad += std::memcmp(&g_obsc[e * NOBS + c], &cl, 4) != 0;
             }
-            const float cl = std::fmin(std::fmax(a, -p.clip_obs), p.clip_obs);
-            bad += std::memcmp(&g_obsc[e * NOBS + c], &cl, 4) != 0;
         }
-    }
-    for (size_t i = 0; i < g_dof.size(); ++i) bad += std::memcmp(&g_dof[i], &dof.host[i], 4) != 0;
+        for (size_t i = 0; i < g_dof.size(); ++i) bad += std::memcmp(&g_dof[i], &dof.host[i], 4) != 0;
+        return 0;
+    };
+    int64_t bad = 0;
+    if (mismatches(bad)) return 2;
     if (bad) { std::fprintf(stderr, "cabi: %lld mismatches over %lld envs\n", (long long)bad, (long long)n); return 1; }
-    std::printf("cabi ok: igx_ant_step, %lld envs, version %d\n", (long long)n, igx_version());
+
+    // The same entry point under stream capture: the call only enqueues a kernel, so it records into a
+    // HIP graph.  A recorded launch repeats its argument values; the draws of the flagged resets stay
+    // fresh through the device-resident counter that the kernel adds to rng_offset.
+    uint64_t *counter = nullptr;
+    HIP_OK(hipMalloc(&counter, sizeof(uint64_t)));
+    igx_loco_params pg = p;
+    pg.rng_offset_dev = counter;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal));
+    const int rcg = igx_ant_step(&pg, &d, n, stream);
+    HIP_OK(hipStreamEndCapture(stream, &graph));
+    if (rcg != IGX_OK) { std::fprintf(stderr, "igx_ant_step under capture: %d %s\n", rcg, igx_last_error_string()); return 1; }
+    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (uint64_t replay = 0; replay < 2; ++replay) {
+        const uint64_t count = 5 + replay;
+        for (int64_t e = 0; e < n; e += 3) reset.host[e] = 1;  // plenty of resets: the draws must match too
+        if (reset.up()) return 2;
+        HIP_OK(hipMemcpyAsync(counter, &count, sizeof count, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipGraphLaunch(exec, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        igx_loco_params ph = p;
+        ph.rng_offset = p.rng_offset + count;
+        if (orc_ant_step(&ph, &h, n) != 0) return 1;
+        if (mismatches(bad)) return 2;
+        if (bad) { std::fprintf(stderr, "cabi: graph replay %llu: %lld mismatches\n", (unsigned long long)replay, (long long)bad); return 1; }
+    }
+    HIP_OK(hipGraphExecDestroy(exec));
+    HIP_OK(hipGraphDestroy(graph));
+    HIP_OK(hipFree(counter));
+    std::printf("cabi ok: igx_ant_step eager and replayed from a graph, %lld envs, version %d\n", (long long)n, igx_version());
     return 0;
 }
