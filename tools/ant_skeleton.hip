@@ -137,6 +137,45 @@ __global__ __launch_bounds__(64) void skel_pol(Bufs b, int64_t ntiles)
     if (lane < 48) { __builtin_nontemporal_store(r[3], (v4f *)(b.up + base * 3) + lane); __builtin_nontemporal_store(r[7], (v4f *)(b.head + base * 3) + lane); }
 }
 
+// Humanoid access pattern (root 13, dof_state 42, dof_force 21, sensors 12, actions 21 floats in; 108-wide
+// rows out; the same per-env scalars), T rows per 64-lane wave, no math and no LDS: every input chunk is
+// loaded, folded into one value and the output chunks are stored.
+struct HBufs { const float *root, *dof, *force, *sens, *act; float *pot, *prev, *up, *head, *rew, *obs; int64_t *reset, *prog, *rnd; };
+template <int T>
+__global__ __launch_bounds__(64) void skel_hum(HBufs b, int64_t ntiles)
+{
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t base = tile * T;
+    v4f acc = {0, 0, 0, 0};
+    auto stream_in = [&](const float *g, int row) {
+        const v4f *g4 = (const v4f *)(g + base * row);
+        const int n4 = T * row / 4;
+#pragma unroll
+        for (int k = 0; k < (n4 + 63) / 64; ++k) {
+            const int i = lane + 64 * k;
+            acc += __builtin_nontemporal_load(g4 + (i < n4 ? i : n4 - 1));
+        }
+    };
+    stream_in(b.root, 13); stream_in(b.dof, 42); stream_in(b.force, 21); stream_in(b.sens, 12); stream_in(b.act, 21);
+    const int e = lane < T ? lane : 0;
+    const float pot = b.pot[base + e];
+    const int64_t rs = b.reset[base + e], pg = b.prog[base + e], rn = b.rnd[base + e];
+    v4f *og = (v4f *)(b.obs + base * 108);
+    constexpr int O4 = T * 108 / 4;
+#pragma unroll
+    for (int k = 0; k < (O4 + 63) / 64; ++k) {
+        const int i = lane + 64 * k;
+        if (i < O4) __builtin_nontemporal_store(acc, og + i);
+    }
+    if (lane < T) {
+        b.pot[base + lane] = pot + acc.x; b.prev[base + lane] = pot; b.rew[base + lane] = pot * 2.0f;
+        b.reset[base + lane] = rs ^ 1; b.prog[base + lane] = pg + 1; b.rnd[base + lane] = rn + 1;
+    }
+    if (lane < T * 3 / 4) { __builtin_nontemporal_store(acc, (v4f *)(b.up + base * 3) + lane); __builtin_nontemporal_store(acc, (v4f *)(b.head + base * 3) + lane); }
+}
+
 template <class F>
 static double time_ms(F f, int iters)
 {
@@ -204,6 +243,28 @@ int main(int argc, char **argv)
     RUN(256, true, false, 1024, "persist_b256_g1024");
     RUN(256, true, false, 2048, "persist_b256_g2048");
     RUN(256, true, true, 2048, "persist_b256_g2048_nt");
+    {   // Humanoid pattern: 960 B per env with randomize both ways (940 in the model)
+        HBufs h[NS];
+        for (int i = 0; i < NS; ++i) {
+            auto A = [&](size_t bytes) {
+                void *p; CHECK(hipMalloc(&p, bytes));
+                if (random) CHECK(hipMemcpy(p, (const char *)host.data() + 4 * ((i * 977 + bytes / 64) % 1024), bytes < host.size() * 4 - 4096 ? bytes : host.size() * 4 - 4096, hipMemcpyHostToDevice));
+                else CHECK(hipMemset(p, 0, bytes));
+                return p; };
+            h[i].root = (float *)A(N * 13 * 4); h[i].dof = (float *)A(N * 42 * 4); h[i].force = (float *)A(N * 21 * 4);
+            h[i].sens = (float *)A(N * 12 * 4); h[i].act = (float *)A(N * 21 * 4);
+            h[i].pot = (float *)A(N * 4); h[i].prev = (float *)A(N * 4); h[i].up = (float *)A(N * 12); h[i].head = (float *)A(N * 12);
+            h[i].rew = (float *)A(N * 4); h[i].obs = (float *)A(N * 432); h[i].reset = (int64_t *)A(N * 8); h[i].prog = (int64_t *)A(N * 8);
+            h[i].rnd = (int64_t *)A(N * 8);
+        }
+        const double hbytes = 940.0 * N;
+        auto emith = [&](const std::string &name, double ms) { printf(", \"%s\": [%.1f, %.0f]", name.c_str(), ms * 1e3, hbytes / ms / 1e6); fflush(stdout); };
+        emith("humanoid_T32", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<32>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        for (int lds : {7000, 10000, 14000, 20000, 28000})
+            emith("humanoid_T32_lds" + std::to_string(lds), time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<32>), dim3((unsigned)(N / 32)), dim3(64), lds, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T64", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<64>), dim3((unsigned)(N / 64)), dim3(64), 0, 0, h[i % NS], N / 64); }, 30));
+        emith("humanoid_T16", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<16>), dim3((unsigned)(N / 16)), dim3(64), 0, 0, h[i % NS], N / 16); }, 30));
+    }
     printf("}\n");
     return 0;
 }
