@@ -142,13 +142,25 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const double *__rest
     const int shift = digit_shift(pass), bits = digit_bits(pass);
     const unsigned long long p0 = s_st.prefix[0], p1 = s_st.prefix[1];
     const bool same = p0 == p1;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const unsigned long long k = key_of(ld_stream(x + i));
+    auto count = [&](double v) {
+        const unsigned long long k = key_of(v);
         const unsigned long long hi = pass == 0 ? 0ull : (k >> (shift + bits));
         const unsigned d = (unsigned)((k >> shift) & ((1u << bits) - 1u));
         if (hi == p0) atomicAdd(&s_hist[0][d], 1u);
         if (!same && hi == p1) atomicAdd(&s_hist[1][d], 1u);
+    };
+    // eight loads in flight per thread: one load per trip would pay the memory latency once per element
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld_stream(x + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) count(v[u]);
     }
+    for (; i < n; i += stride) count(ld_stream(x + i));
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * QBINS; i += 256) {
         const unsigned c = (&s_hist[0][0])[i];
@@ -204,7 +216,8 @@ extern "C" int igx_quantile_histogram(const double *x, int64_t n, void *workspac
     if (n < 0) return fail(IGX_E_SIZE, "igx_quantile_histogram: negative n");
     if (n > 0 && !x) return fail(IGX_E_NULL, "igx_quantile_histogram: x is NULL");
     // an empty shard contributes nothing but still advances its copy of the state
-    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    static const int per_thread = tuning_int("IGX_QUANTILE_PER_THREAD", 16);
+    int64_t blocks = (n + 256 * (int64_t)per_thread - 1) / (256 * (int64_t)per_thread);
     blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
     hipLaunchKernelGGL(quantile_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n,
                        static_cast<QuantileState *>(workspace), (int)pass);
