@@ -675,8 +675,10 @@ int igx_clamp(const float *x, float lo, float hi, float *out, int64_t count, igx
  * :119-121, :289-293) captures selected observation columns of every
  * environment at every step with obs.clone().cpu() and an O(T^2) torch.cat.
  * Here a capture is a gather kernel on the producer's stream into a device
- * staging slot, and a hipMemcpyAsync into pinned host memory on the recorder's
- * own side stream, ordered by events.  A slot batches consecutive steps up to about
+ * staging slot, and a copy into pinned host memory on the recorder's own side
+ * stream, ordered by events.  The copy is a kernel of a few workgroups writing
+ * through the host mapping: the runtime's device-to-host copy is a blit kernel
+ * that fills the GPU for the whole transfer and holds the producer's kernels up.  A slot batches consecutive steps up to about
  * 128 MiB (at most 64 steps) per copy; the producer waits only when the ring of slots is full, i.e. when
  * it produces faster than the host link drains.
  * Host layout: [max_steps][num_cols][n_rows] fp32 (step-major), pinned.

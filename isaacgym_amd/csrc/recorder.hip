@@ -5,7 +5,8 @@
 //                                 gather kernel -> step k % B of staging slot s = (k / B) % S
 //                                 record(slot_full[s])               (last capture of the slot's batch)
 //               copy stream       wait(slot_full[s])
-//                                 hipMemcpyAsync(host + first * slab, slot, B slabs, D2H)   (pinned, contiguous)
+//                                 drain kernel on 16 workgroups: slot -> host + first * slab (pinned, mapped,
+//                                 B slabs, contiguous); IGX_RECORDER_DRAIN_BLOCKS=0 selects hipMemcpyAsync
 //                                 record(slot_free[s])
 //
 // A slot batches B consecutive steps (B slabs of [num_cols][n_rows] are contiguous on the host
@@ -31,6 +32,8 @@ struct igx_recorder {
     int32_t *d_cols = nullptr;
     float *d_ring = nullptr;   // [ring_slots][batch][num_cols][n_rows]
     float *h_data = nullptr;   // [max_steps][num_cols][n_rows], pinned
+    float *h_data_dev = nullptr;  // the same memory as the device addresses it
+    int drain_blocks = 0;      // > 0: copy with recorder_drain_kernel on that many workgroups; 0: hipMemcpyAsync
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> slot_full, slot_free;
 };
@@ -48,6 +51,19 @@ __global__ __launch_bounds__(256) void recorder_gather_kernel(const float *__res
     if (row >= n_rows) return;
     const float *r = src + row * row_width;
     for (int c = 0; c < num_cols; ++c) st_stream(out + (int64_t)c * n_rows + row, r[cols[c]]);
+}
+
+// staging slot -> pinned host memory by a kernel of a few workgroups (the host buffer is mapped into the
+// device's address space).  The runtime's own device-to-host copy is a blit kernel that fills the whole
+// GPU for the duration of the transfer, and the producer's kernels queue behind it; a narrow kernel leaves
+// the compute units to the producer while it keeps the link busy.
+__global__ __launch_bounds__(256) void recorder_drain_kernel(const v4f *__restrict__ src, v4f *__restrict__ host_dst,
+                                                             int64_t n4, const float *__restrict__ src_tail,
+                                                             float *__restrict__ dst_tail, int tail)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) host_dst[i] = ld_stream(src + i);
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
 static int hip_fail(hipError_t e, const char *what)
@@ -96,7 +112,10 @@ extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t r
     REC_HIP(hipMalloc(&r->d_cols, sizeof(int32_t) * num_cols), "hipMalloc(cols)");
     REC_HIP(hipMemcpy(r->d_cols, cols, sizeof(int32_t) * num_cols, hipMemcpyHostToDevice), "hipMemcpy(cols)");
     REC_HIP(hipMalloc(&r->d_ring, sizeof(float) * slab * r->batch * ring_slots), "hipMalloc(ring)");
-    REC_HIP(hipHostMalloc(&r->h_data, sizeof(float) * slab * max_steps, hipHostMallocDefault), "hipHostMalloc");
+    REC_HIP(hipHostMalloc(&r->h_data, sizeof(float) * slab * max_steps, hipHostMallocMapped), "hipHostMalloc");
+    r->drain_blocks = tuning_int("IGX_RECORDER_DRAIN_BLOCKS", 16);
+    if (r->drain_blocks < 0 || r->drain_blocks > 4096) r->drain_blocks = 0;
+    if (r->drain_blocks > 0) REC_HIP(hipHostGetDevicePointer((void **)&r->h_data_dev, r->h_data, 0), "hipHostGetDevicePointer");
     REC_HIP(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
     for (int s = 0; s < ring_slots; ++s) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -126,9 +145,24 @@ static int recorder_flush(igx_recorder *r, hipStream_t ps)
     const int64_t count = r->steps - r->flushed;
     REC_HIP(hipEventRecord(r->slot_full[slot], ps), "record(slot_full)");
     REC_HIP(hipStreamWaitEvent(r->copy_stream, r->slot_full[slot], 0), "wait(slot_full)");
-    REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * slab * count, hipMemcpyDeviceToHost,
-                           r->copy_stream),
-            "hipMemcpyAsync");
+    if (r->drain_blocks > 0) {
+        const int64_t floats = slab * count, n4 = floats / 4;  // slot starts and host offsets are multiples of 16 bytes
+        const bool vec = aligned16(stage) && aligned16(r->h_data_dev + slab * r->flushed);
+        hipLaunchKernelGGL(recorder_drain_kernel, dim3((unsigned)r->drain_blocks), dim3(256), 0, r->copy_stream,
+                           reinterpret_cast<const v4f *>(stage), reinterpret_cast<v4f *>(r->h_data_dev + slab * r->flushed),
+                           vec ? n4 : 0, stage + (vec ? 4 * n4 : 0), r->h_data_dev + slab * r->flushed + (vec ? 4 * n4 : 0),
+                           vec ? (int)(floats - 4 * n4) : 0);
+        if (!vec) {  // odd slab sizes: the plain copy
+            REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * floats, hipMemcpyDeviceToHost,
+                                   r->copy_stream), "hipMemcpyAsync");
+        }
+        int rc = launch_status("igx_recorder: drain");
+        if (rc != IGX_OK) return rc;
+    } else {
+        REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * slab * count, hipMemcpyDeviceToHost,
+                               r->copy_stream),
+                "hipMemcpyAsync");
+    }
     REC_HIP(hipEventRecord(r->slot_free[slot], r->copy_stream), "record(slot_free)");
     r->flushed = r->steps;
     return IGX_OK;
