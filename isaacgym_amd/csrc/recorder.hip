@@ -145,21 +145,16 @@ static int recorder_flush(igx_recorder *r, hipStream_t ps)
     const int64_t count = r->steps - r->flushed;
     REC_HIP(hipEventRecord(r->slot_full[slot], ps), "record(slot_full)");
     REC_HIP(hipStreamWaitEvent(r->copy_stream, r->slot_full[slot], 0), "wait(slot_full)");
-    if (r->drain_blocks > 0) {
-        const int64_t floats = slab * count, n4 = floats / 4;  // slot starts and host offsets are multiples of 16 bytes
-        const bool vec = aligned16(stage) && aligned16(r->h_data_dev + slab * r->flushed);
+    const int64_t floats = slab * count, n4 = floats / 4;
+    float *dst_dev = r->h_data_dev ? r->h_data_dev + slab * r->flushed : nullptr;
+    if (dst_dev && aligned16(stage) && aligned16(dst_dev)) {
         hipLaunchKernelGGL(recorder_drain_kernel, dim3((unsigned)r->drain_blocks), dim3(256), 0, r->copy_stream,
-                           reinterpret_cast<const v4f *>(stage), reinterpret_cast<v4f *>(r->h_data_dev + slab * r->flushed),
-                           vec ? n4 : 0, stage + (vec ? 4 * n4 : 0), r->h_data_dev + slab * r->flushed + (vec ? 4 * n4 : 0),
-                           vec ? (int)(floats - 4 * n4) : 0);
-        if (!vec) {  // odd slab sizes: the plain copy
-            REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * floats, hipMemcpyDeviceToHost,
-                                   r->copy_stream), "hipMemcpyAsync");
-        }
+                           reinterpret_cast<const v4f *>(stage), reinterpret_cast<v4f *>(dst_dev), n4, stage + 4 * n4,
+                           dst_dev + 4 * n4, (int)(floats - 4 * n4));
         int rc = launch_status("igx_recorder: drain");
         if (rc != IGX_OK) return rc;
-    } else {
-        REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * slab * count, hipMemcpyDeviceToHost,
+    } else {  // odd row counts put slabs at addresses that are not multiples of 16 bytes: the runtime's copy
+        REC_HIP(hipMemcpyAsync(r->h_data + slab * r->flushed, stage, sizeof(float) * floats, hipMemcpyDeviceToHost,
                                r->copy_stream),
                 "hipMemcpyAsync");
     }
