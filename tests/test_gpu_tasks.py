@@ -455,3 +455,24 @@ def test_amp_reset_flagged_equals_the_host_path_on_the_same_draws(motion_lib, st
         assert torch.equal(x[keep], untouched[k][keep]), k
 
 
+
+
+def test_amp_demo_batches_stream_to_the_host(motion_lib):
+    """Imitation batches (fetch_amp_obs_demo: motion sampling, slerp, AMP observations of two consecutive
+    frames) captured step after step by the recorder: what lands in pinned host memory is what the task returned."""
+    from isaacgym_amd.recorder import TrajectoryRecorder
+    n, steps = 512, 9
+    task = _amp_task(motion_lib, 64)
+    width = task.get_num_amp_obs()
+    rec = TrajectoryRecorder(n, width, {"c%d" % c: c for c in range(width)}, steps, DEV)
+    np.random.seed(5)
+    want = []
+    for _ in range(steps):
+        demo = task.fetch_amp_obs_demo(n)          # [512, 210], reused buffer
+        rec.capture(demo)
+        want.append(demo.clone())
+    got = rec.finish()
+    rec.close()
+    for c in (0, 1, 104, 105, width - 1):
+        assert torch.equal(got["c%d" % c], torch.stack([w[:, c] for w in want], 1).cpu()), c
+    assert len({float(w.sum()) for w in want}) == steps    # every batch was a new sample
