@@ -141,7 +141,66 @@ __global__ __launch_bounds__(64) void skel_pol(Bufs b, int64_t ntiles)
 // rows out; the same per-env scalars), T rows per 64-lane wave, no math and no LDS: every input chunk is
 // loaded, folded into one value and the output chunks are stored.
 struct HBufs { const float *root, *dof, *force, *sens, *act; float *pot, *prev, *up, *head, *rew, *obs; int64_t *reset, *prog, *rnd; };
-template <int T>
+// the same streams, but the loaded chunks go through an LDS image of the output tile (vector writes, a
+// wave barrier, vector reads) before they are stored: the staging structure of the real kernel without its math
+template <int T, int VAR = 0>
+__global__ __launch_bounds__(64) void skel_hum_lds(HBufs b, int64_t ntiles)
+{
+    __shared__ __attribute__((aligned(16))) float s_tile[T * 108];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int64_t base = tile * T;
+    constexpr int O4 = T * 108 / 4;
+    int slot = lane;
+    float pot1 = 0; int64_t rs1 = 0, pg1 = 0, rn1 = 0;
+    if (VAR & 1) {
+        const int e1 = lane < T ? lane : 0;
+        pg1 = __builtin_nontemporal_load(b.prog + base + e1); rs1 = __builtin_nontemporal_load(b.reset + base + e1);
+        pot1 = __builtin_nontemporal_load(b.pot + base + e1); rn1 = __builtin_nontemporal_load(b.rnd + base + e1);
+    }
+    if (VAR & 4) {  // first, default policy
+        const int e1 = lane < T ? lane : 0;
+        pg1 = b.prog[base + e1]; rs1 = b.reset[base + e1]; pot1 = b.pot[base + e1]; rn1 = b.rnd[base + e1];
+    }
+    auto stream_in = [&](const float *g, int row) {
+        const v4f *g4 = (const v4f *)(g + base * row);
+        const int n4 = T * row / 4;
+        v4f r[11];
+        const int iters = (n4 + 63) / 64;
+        for (int k = 0; k < iters; ++k) { const int i = lane + 64 * k; r[k] = __builtin_nontemporal_load(g4 + (i < n4 ? i : n4 - 1)); }
+        for (int k = 0; k < iters; ++k) { if (slot < O4) *(v4f *)(s_tile + 4 * slot) = r[k]; slot += 64; }
+    };
+    stream_in(b.root, 13); stream_in(b.dof, 42); stream_in(b.force, 21); stream_in(b.sens, 12); stream_in(b.act, 21);
+    const int e = lane < T ? lane : 0;
+    float pot; int64_t rs, pg, rn;
+    if (VAR & 5) { pot = pot1; rs = rs1; pg = pg1; rn = rn1; }
+    else if (VAR & 8) {  // last, non-temporal
+        pot = __builtin_nontemporal_load(b.pot + base + e); rs = __builtin_nontemporal_load(b.reset + base + e);
+        pg = __builtin_nontemporal_load(b.prog + base + e); rn = __builtin_nontemporal_load(b.rnd + base + e);
+    } else { pot = b.pot[base + e]; rs = b.reset[base + e]; pg = b.prog[base + e]; rn = b.rnd[base + e]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v4f *og = (v4f *)(b.obs + base * 108);
+#pragma unroll
+    for (int k = 0; k < (O4 + 63) / 64; ++k) {
+        const int i = lane + 64 * k;
+        if (i < O4) __builtin_nontemporal_store(*(const v4f *)(s_tile + 4 * i), og + i);
+    }
+    const v4f acc = *(const v4f *)(s_tile + 4 * lane);
+    if (lane < T) {
+        if (VAR & 2) {
+            __builtin_nontemporal_store(pot + acc.x, b.pot + base + lane); __builtin_nontemporal_store(pot, b.prev + base + lane);
+            __builtin_nontemporal_store(pot * 2.0f, b.rew + base + lane); __builtin_nontemporal_store(rs ^ 1, b.reset + base + lane);
+            __builtin_nontemporal_store(pg + 1, b.prog + base + lane); __builtin_nontemporal_store(rn + 1, b.rnd + base + lane);
+        } else {
+            b.pot[base + lane] = pot + acc.x; b.prev[base + lane] = pot; b.rew[base + lane] = pot * 2.0f;
+            b.reset[base + lane] = rs ^ 1; b.prog[base + lane] = pg + 1; b.rnd[base + lane] = rn + 1;
+        }
+    }
+    if (lane < T * 3 / 4) { __builtin_nontemporal_store(acc, (v4f *)(b.up + base * 3) + lane); __builtin_nontemporal_store(acc, (v4f *)(b.head + base * 3) + lane); }
+}
+
+template <int T, int DELAY = 0>
 __global__ __launch_bounds__(64) void skel_hum(HBufs b, int64_t ntiles)
 {
     const int lane = threadIdx.x;
@@ -159,6 +218,12 @@ __global__ __launch_bounds__(64) void skel_hum(HBufs b, int64_t ntiles)
         }
     };
     stream_in(b.root, 13); stream_in(b.dof, 42); stream_in(b.force, 21); stream_in(b.sens, 12); stream_in(b.act, 21);
+    if (DELAY) {  // a dependent chain of DELAY fused multiply-adds between the loads and the stores: the compute phase
+        float x = acc.x;
+#pragma unroll 8
+        for (int i = 0; i < DELAY; ++i) x = __builtin_fmaf(x, 1.0000001f, 0.5f);
+        acc.x = x;
+    }
     const int e = lane < T ? lane : 0;
     const float pot = b.pot[base + e];
     const int64_t rs = b.reset[base + e], pg = b.prog[base + e], rn = b.rnd[base + e];
@@ -262,6 +327,23 @@ int main(int argc, char **argv)
         emith("humanoid_T32", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<32>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
         for (int lds : {7000, 10000, 14000, 20000, 28000})
             emith("humanoid_T32_lds" + std::to_string(lds), time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<32>), dim3((unsigned)(N / 32)), dim3(64), lds, 0, h[i % NS], N / 32); }, 30));
+        for (int lds : {0, 10000, 14000, 20000})
+            emith("humanoid_T32_delay2000_lds" + std::to_string(lds), time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<32, 2000>), dim3((unsigned)(N / 32)), dim3(64), lds, 0, h[i % NS], N / 32); }, 30));
+        for (int lds : {0, 14000})
+            emith("humanoid_T32_delay4000_lds" + std::to_string(lds), time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<32, 4000>), dim3((unsigned)(N / 32)), dim3(64), lds, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 0>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds_flags_first_nt", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 1>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds_scalar_stores_nt", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 2>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds_both", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 3>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds_flags_first_plain", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 4>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds_flags_last_nt", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 8>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        {   // outputs and per-environment state shared by all input sets, as a task that steps in place has them
+            HBufs g[NS];
+            for (int i = 0; i < NS; ++i) { g[i] = h[i]; g[i].pot = h[0].pot; g[i].prev = h[0].prev; g[i].up = h[0].up; g[i].head = h[0].head;
+                                           g[i].rew = h[0].rew; g[i].obs = h[0].obs; g[i].reset = h[0].reset; g[i].prog = h[0].prog; g[i].rnd = h[0].rnd; }
+            emith("humanoid_T32_through_lds_shared_outputs", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 0>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, g[i % NS], N / 32); }, 30));
+        }
+        emith("humanoid_T32_through_lds_again", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 0>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
         emith("humanoid_T64", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<64>), dim3((unsigned)(N / 64)), dim3(64), 0, 0, h[i % NS], N / 64); }, 30));
         emith("humanoid_T16", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<16>), dim3((unsigned)(N / 16)), dim3(64), 0, 0, h[i % NS], N / 16); }, 30));
     }
