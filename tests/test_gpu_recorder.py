@@ -102,3 +102,19 @@ def test_recorder_batches_partial_flushes_and_ring_wrap(n, ring):
     with pytest.raises(IgxError):
         rec.capture(buf)   # max_steps taken
     rec.close()
+
+
+@pytest.mark.parametrize("blocks", ["0", "3", "64"])
+def test_both_copy_paths_land_the_same_bytes(blocks, monkeypatch):
+    """IGX_RECORDER_DRAIN_BLOCKS: 0 = the runtime's device-to-host copy, otherwise the narrow copy kernel."""
+    monkeypatch.setenv("IGX_RECORDER_DRAIN_BLOCKS", blocks)
+    n, width, steps = 4096, 6, 40
+    rec = TrajectoryRecorder(n, width, dict(a=1, b=4, c=5), steps, DEV, ring_slots=2)
+    gen = torch.Generator(device=DEV).manual_seed(int(blocks))
+    frames = [torch.randn(n, width, generator=gen, device=DEV) for _ in range(steps)]
+    for f in frames:
+        rec.capture(f)
+    got = rec.finish()
+    rec.close()
+    for name, col in (("a", 1), ("b", 4), ("c", 5)):
+        assert torch.equal(got[name], torch.stack([f[:, col] for f in frames], 1).cpu()), name

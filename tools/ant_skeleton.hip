@@ -294,6 +294,8 @@ int main(int argc, char **argv)
     RUN(256, false, true, (unsigned)(ntiles / 4), "oneshot_b256_nt");
     RUN(512, false, false, (unsigned)(ntiles / 8), "oneshot_b512");
     RUN(1024, false, false, (unsigned)(ntiles / 16), "oneshot_b1024");
+    for (int lds : {8000, 16000, 28000, 40000})  // fewer resident waves through an LDS reservation
+        emit("oneshot_w64_nt_lds" + std::to_string(lds), time_ms([&](int i) { hipLaunchKernelGGL((skel<64, false, true>), dim3((unsigned)ntiles), dim3(64), lds, 0, s[i % NS], ntiles); }, 30));
 #define RUNS(TPB, NT, GRID, NAME) emit(NAME, time_ms([&](int i) { hipLaunchKernelGGL((skel_split<TPB, NT>), dim3(GRID), dim3(TPB), 0, 0, s[i % NS], ntiles); }, 30))
     RUNS(64, true, (unsigned)ntiles, "split_w64_nt");
     RUNS(256, true, (unsigned)(ntiles / 4), "split_b256_nt");
