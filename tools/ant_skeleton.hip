@@ -181,13 +181,19 @@ __global__ __launch_bounds__(64) void skel_hum_lds(HBufs b, int64_t ntiles)
     } else { pot = b.pot[base + e]; rs = b.reset[base + e]; pg = b.prog[base + e]; rn = b.rnd[base + e]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     v4f *og = (v4f *)(b.obs + base * 108);
+    const v4f acc = *(const v4f *)(s_tile + 4 * lane);
+    if ((VAR & 16) && lane < T) {  // the per-environment scalars stored ahead of the wide drain
+        __builtin_nontemporal_store(pot + acc.x, b.pot + base + lane); __builtin_nontemporal_store(pot, b.prev + base + lane);
+        __builtin_nontemporal_store(pot * 2.0f, b.rew + base + lane); __builtin_nontemporal_store(rs ^ 1, b.reset + base + lane);
+        __builtin_nontemporal_store(pg + 1, b.prog + base + lane); __builtin_nontemporal_store(rn + 1, b.rnd + base + lane);
+    }
 #pragma unroll
     for (int k = 0; k < (O4 + 63) / 64; ++k) {
         const int i = lane + 64 * k;
         if (i < O4) __builtin_nontemporal_store(*(const v4f *)(s_tile + 4 * i), og + i);
     }
-    const v4f acc = *(const v4f *)(s_tile + 4 * lane);
-    if (lane < T) {
+    if (VAR & 16) {
+    } else if (lane < T) {
         if (VAR & 2) {
             __builtin_nontemporal_store(pot + acc.x, b.pot + base + lane); __builtin_nontemporal_store(pot, b.prev + base + lane);
             __builtin_nontemporal_store(pot * 2.0f, b.rew + base + lane); __builtin_nontemporal_store(rs ^ 1, b.reset + base + lane);
@@ -345,6 +351,8 @@ int main(int argc, char **argv)
                                            g[i].rew = h[0].rew; g[i].obs = h[0].obs; g[i].reset = h[0].reset; g[i].prog = h[0].prog; g[i].rnd = h[0].rnd; }
             emith("humanoid_T32_through_lds_shared_outputs", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 0>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, g[i % NS], N / 32); }, 30));
         }
+        emith("humanoid_T32_through_lds_scalars_before_drain", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 16>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
+        emith("humanoid_T32_through_lds_scalars_before_drain_flags_first", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 17>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
         emith("humanoid_T32_through_lds_again", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum_lds<32, 0>), dim3((unsigned)(N / 32)), dim3(64), 0, 0, h[i % NS], N / 32); }, 30));
         emith("humanoid_T64", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<64>), dim3((unsigned)(N / 64)), dim3(64), 0, 0, h[i % NS], N / 64); }, 30));
         emith("humanoid_T16", time_ms([&](int i) { hipLaunchKernelGGL((skel_hum<16>), dim3((unsigned)(N / 16)), dim3(64), 0, 0, h[i % NS], N / 16); }, 30));
