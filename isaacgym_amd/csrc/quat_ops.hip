@@ -12,6 +12,7 @@
 
 #include "igx_device.hpp"
 #include "igx_host.hpp"
+#include "igx_tile.hpp"
 
 namespace igx {
 
@@ -453,21 +454,63 @@ __global__ __launch_bounds__(256) void rand_float_kernel(float span, float lower
 enum { AFF_SCALE = 0, AFF_UNSCALE = 1, AFF_CLAMP = 2, AFF_SCALE_TRANSFORM = 3, AFF_UNSCALE_TRANSFORM = 4 };
 
 template <int KIND>
+__device__ __forceinline__ float affine1(float v, float lo, float hi)
+{
+    if (KIND == AFF_SCALE) return scale(v, lo, hi);            // :234-236
+    if (KIND == AFF_UNSCALE) return unscale(v, lo, hi);        // :239-241
+    if (KIND == AFF_SCALE_TRANSFORM) return 2.0f * (v - (lo + hi) * 0.5f) / (hi - lo);    // :292-310
+    if (KIND == AFF_UNSCALE_TRANSFORM) return v * (hi - lo) * 0.5f + (lo + hi) * 0.5f;    // :313-331
+    return tensor_clamp(v, lo, hi);                            // :228-230, saturate :333-348
+}
+
+// VEC: AFF_U x four consecutive elements per lane through 16-byte loads and stores (total % 4 == 0,
+// x and out 16-byte aligned), the per-column bounds staged in LDS when they fit; otherwise one
+// element per lane.
+constexpr int AFF_U = 4;
+constexpr int AFF_LDS_COLS = 1024;
+
+template <int KIND, bool VEC>
 __global__ __launch_bounds__(256) void affine_kernel(const float *__restrict__ x, const float *__restrict__ lower,
                                                      const float *__restrict__ upper, float *__restrict__ out,
                                                      int64_t total, int d)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int col = (int)(i % d);
-    const float lo = lower[col], hi = upper[col], v = x[i];
-    float r;
-    if (KIND == AFF_SCALE) r = scale(v, lo, hi);            // :234-236
-    else if (KIND == AFF_UNSCALE) r = unscale(v, lo, hi);   // :239-241
-    else if (KIND == AFF_SCALE_TRANSFORM) r = 2.0f * (v - (lo + hi) * 0.5f) / (hi - lo);    // :292-310
-    else if (KIND == AFF_UNSCALE_TRANSFORM) r = v * (hi - lo) * 0.5f + (lo + hi) * 0.5f;    // :313-331
-    else r = tensor_clamp(v, lo, hi);                       // :228-230, saturate :333-348
-    out[i] = r;
+    if (VEC) {
+        __shared__ float s_lo[AFF_LDS_COLS], s_hi[AFF_LDS_COLS];
+        const int64_t t0 = (int64_t)blockIdx.x * (256 * AFF_U) + threadIdx.x;
+        v4f v[AFF_U];
+#pragma unroll
+        for (int u = 0; u < AFF_U; ++u) {
+            const int64_t t = t0 + u * 256;
+            v[u] = ld_stream(reinterpret_cast<const v4f *>(x) + (4 * t < total ? t : 0));
+        }
+        const bool staged = d <= AFF_LDS_COLS;
+        if (staged) {
+            for (int c = threadIdx.x; c < d; c += 256) {
+                s_lo[c] = lower[c];
+                s_hi[c] = upper[c];
+            }
+            __syncthreads();
+        }
+        const float *lo = staged ? s_lo : lower, *hi = staged ? s_hi : upper;
+#pragma unroll
+        for (int u = 0; u < AFF_U; ++u) {
+            const int64_t t = t0 + u * 256, i = 4 * t;
+            if (i >= total) break;
+            int col = total <= 0x7fffffffLL ? (int)((unsigned)i % (unsigned)d) : (int)(i % d);
+            float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                e[k] = affine1<KIND>(e[k], lo[col], hi[col]);
+                if (++col == d) col = 0;
+            }
+            st_stream(reinterpret_cast<v4f *>(out) + t, v4f{e[0], e[1], e[2], e[3]});
+        }
+    } else {
+        const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (t >= total) return;
+        const int col = (int)(t % d);
+        out[t] = affine1<KIND>(x[t], lower[col], upper[col]);
+    }
 }
 
 template <int KIND>
@@ -478,8 +521,13 @@ static int run_affine(const char *who, const float *x, const float *lower, const
     if (n == 0) return IGX_OK;
     if (!x || !lower || !upper || !out) return fail(IGX_E_NULL, "%s: NULL argument", who);
     const int64_t total = n * d;
-    hipLaunchKernelGGL((affine_kernel<KIND>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, lower, upper, out, total, (int)d);
+    if (total % 4 == 0 && aligned16(x) && aligned16(out)) {
+        hipLaunchKernelGGL((affine_kernel<KIND, true>), dim3((unsigned)((total / 4 + 256 * AFF_U - 1) / (256 * AFF_U))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, lower, upper, out, total, (int)d);
+    } else {
+        hipLaunchKernelGGL((affine_kernel<KIND, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, lower, upper, out, total, (int)d);
+    }
     return launch_status(who);
 }
 

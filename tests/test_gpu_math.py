@@ -47,6 +47,21 @@ def test_affine_golden(name):
     assert H.bit_equal_fraction(got, g[name]) == 1.0
 
 
+@pytest.mark.parametrize("n,d,offset", [(1, 3, 0), (257, 7, 0), (4099, 8, 0), (4099, 8, 1), (100003, 21, 0), (65536, 20, 0)])
+def test_affine_vs_oracle_shapes(n, d, offset):
+    """Both launch shapes of the affine kernels (four elements per lane when the element count is a multiple of
+    four and the bases are 16-byte aligned, one per lane otherwise), bit for bit against the CPU checker."""
+    gen = torch.Generator(device=DEV).manual_seed(n + d)
+    flat = torch.randn(n * d + offset, generator=gen, device=DEV)
+    x = flat[offset:].view(n, d)  # offset 1: a base that is only 4-byte aligned
+    lo = -torch.rand(d, generator=gen, device=DEV) - 0.1
+    hi = torch.rand(d, generator=gen, device=DEV) + 0.1
+    for name in AFFINE:
+        got = getattr(tj, name)(x, lo, hi).cpu().numpy()
+        ref = oracle.affine(name, x.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy())
+        assert H.bit_equal_fraction(got, ref) == 1.0, name
+
+
 @pytest.mark.parametrize("n", [0, 1, 255, 257, 300001])
 def test_rowwise_vs_oracle_sizes(n):
     gen = torch.Generator(device=DEV).manual_seed(n + 5)

@@ -103,6 +103,37 @@ def main():
         report("ant_imitate_observe", timed(lambda i: ops.ant_imitate_observe(p, sets[i % 3], im, n), a.steps), 556 + 24)
         report("quantile_f64", timed(lambda i: ops.quantile_f64(pd, 0.99, ws), a.steps), 8 * 6)
         del sets
+    if on("math"):
+        # torch_jit_utils kernels on 2^22 rows (inputs rotate over three sets so that no call re-reads cached lines);
+        # bytes per row = every input row read once + every output row written once
+        from isaacgym_amd.utils import torch_jit_utils as tj
+        m = 1 << 22
+        g = torch.Generator(device=DEV).manual_seed(4)
+
+        def quats():
+            q = torch.randn(m, 4, device=DEV, generator=g)
+            return q / q.norm(dim=-1, keepdim=True)
+
+        def vecs(w=3):
+            return torch.randn(m, w, device=DEV, generator=g)
+
+        Q = [(quats(), quats()) for _ in range(3)]
+        V = [(vecs(), vecs(), vecs(), vecs()) for _ in range(3)]
+        T = [torch.rand(m, 1, device=DEV, generator=g) for _ in range(3)]
+        report("quat_mul", timed(lambda i: tj.quat_mul(*Q[i % 3]), a.steps), 48, m)
+        report("quat_rotate", timed(lambda i: tj.quat_rotate(Q[i % 3][0], V[i % 3][0]), a.steps), 40, m)
+        report("slerp", timed(lambda i: tj.slerp(Q[i % 3][0], Q[i % 3][1], T[i % 3]), a.steps), 52, m)
+        report("quat_to_tan_norm", timed(lambda i: tj.quat_to_tan_norm(Q[i % 3][0]), a.steps), 40, m)
+        report("quat_to_exp_map", timed(lambda i: tj.quat_to_exp_map(Q[i % 3][1]), a.steps), 28, m)
+        report("get_euler_xyz", timed(lambda i: tj.get_euler_xyz(Q[i % 3][0]), a.steps), 28, m)
+        report("tf_combine", timed(lambda i: tj.tf_combine(Q[i % 3][0], V[i % 3][0], Q[i % 3][1], V[i % 3][1]), a.steps), 84, m)
+        report("compute_heading_and_up", timed(lambda i: tj.compute_heading_and_up(
+            Q[i % 3][0], Q[i % 3][1], V[i % 3][0], V[i % 3][1], V[i % 3][2], 2), a.steps), 56 + 48, m)
+        report("compute_rot", timed(lambda i: tj.compute_rot(Q[i % 3][0], *V[i % 3]), a.steps), 64 + 40, m)
+        lo, hi = -torch.rand(8, device=DEV) - 0.1, torch.rand(8, device=DEV) + 0.1
+        X = [vecs(8) for _ in range(3)]
+        report("unscale", timed(lambda i: tj.unscale(X[i % 3], lo, hi), a.steps), 64, m)
+        del Q, V, T, X
     if on("episode"):
         from isaacgym_amd.episode_stats import EpisodeStats
         es = EpisodeStats(n, DEV)
