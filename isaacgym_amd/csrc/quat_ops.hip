@@ -99,43 +99,91 @@ struct OpCalcHeadingQuatInv {  // :656-667
     }
 };
 
-template <int W>
-__device__ __forceinline__ void slab_in(const float *__restrict__ g, float *s, int64_t base, int nvalid, int tid)
-{
-    if (W == 0) return;
-    const float *src = g + base * W;
-    const int count = nvalid * W;
-    if (nvalid == QTILE && (W * QTILE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
-        using v4f = float __attribute__((ext_vector_type(4)));
-        for (int k = tid; k < count / 4; k += QTILE)
-            *reinterpret_cast<v4f *>(s + 4 * k) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src) + k);
-    } else {
-        for (int k = tid; k < count; k += QTILE) s[k] = src[k];
+// One slab of RT rows of W floats, global -> registers -> LDS in two steps, so that a block has the
+// loads of all its input arrays in flight before it waits for the first.
+template <int W, int RT>
+struct Slab {
+    static constexpr int N4 = RT * W / 4;
+    static constexpr int IT = W ? (N4 + QTILE - 1) / QTILE : 1;
+    using v4f = float __attribute__((ext_vector_type(4)));
+    v4f r[IT];
+    __device__ __forceinline__ void load(const float *__restrict__ src, int tid)
+    {
+        if (W == 0) return;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int k = tid + it * QTILE;
+            if ((it + 1) * QTILE <= N4 || k < N4) r[it] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src) + k);
+        }
     }
-}
+    __device__ __forceinline__ void store(float *s, int tid) const
+    {
+        if (W == 0) return;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int k = tid + it * QTILE;
+            if ((it + 1) * QTILE <= N4 || k < N4) *reinterpret_cast<v4f *>(s + 4 * k) = r[it];
+        }
+    }
+};
+
+__device__ __forceinline__ bool dev_aligned16_or_null(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// TPB tiles of QTILE rows per block: a block's lifetime is one memory round trip, so the bytes it
+// moves per trip set the rate; more rows per block as long as the LDS still holds several blocks per CU.
+template <class Op>
+struct RowwiseShape {
+    static constexpr int WSUM = (Op::A ? Op::A : 1) + (Op::B ? Op::B : 1) + (Op::C ? Op::C : 1) + Op::O;
+    static constexpr int TPB = WSUM <= 8 ? 4 : 2;
+    static constexpr int RT = QTILE * TPB;
+};
 
 template <class Op>
 __global__ __launch_bounds__(QTILE) void rowwise_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                         const float *__restrict__ c, float *__restrict__ out, int64_t n)
 {
-    __shared__ __align__(16) float sa[QTILE * (Op::A ? Op::A : 1)];
-    __shared__ __align__(16) float sb[QTILE * (Op::B ? Op::B : 1)];
-    __shared__ __align__(16) float sc[QTILE * (Op::C ? Op::C : 1)];
-    __shared__ __align__(16) float so[QTILE * Op::O];
+    constexpr int RT = RowwiseShape<Op>::RT, TPB = RowwiseShape<Op>::TPB;
+    __shared__ __align__(16) float sa[RT * (Op::A ? Op::A : 1)];
+    __shared__ __align__(16) float sb[RT * (Op::B ? Op::B : 1)];
+    __shared__ __align__(16) float sc[RT * (Op::C ? Op::C : 1)];
+    __shared__ __align__(16) float so[RT * Op::O];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * QTILE;
-    const int nvalid = (n - base >= QTILE) ? QTILE : (int)(n - base);
-    slab_in<Op::A>(a, sa, base, nvalid, tid);
-    slab_in<Op::B>(b, sb, base, nvalid, tid);
-    slab_in<Op::C>(c, sc, base, nvalid, tid);
-    __syncthreads();
-    if (tid < nvalid) Op::compute(sa + tid * Op::A, sb + tid * Op::B, sc + tid * Op::C, so + tid * Op::O);
-    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RT;
+    const int nvalid = (n - base >= RT) ? RT : (int)(n - base);
+    const float *ga = a + base * Op::A, *gb = Op::B ? b + base * Op::B : nullptr, *gc = Op::C ? c + base * Op::C : nullptr;
     float *dst = out + base * Op::O;
+    const bool fast = nvalid == RT && dev_aligned16_or_null(ga) && dev_aligned16_or_null(gb) && dev_aligned16_or_null(gc);
+    if (fast) {
+        Slab<Op::A, RT> ra;
+        Slab<Op::B, RT> rb;
+        Slab<Op::C, RT> rc;
+        ra.load(ga, tid);
+        rb.load(gb, tid);
+        rc.load(gc, tid);
+        ra.store(sa, tid);
+        rb.store(sb, tid);
+        rc.store(sc, tid);
+    } else {
+        for (int k = tid; k < nvalid * Op::A; k += QTILE) sa[k] = ga[k];
+        for (int k = tid; k < nvalid * Op::B; k += QTILE) sb[k] = gb[k];
+        for (int k = tid; k < nvalid * Op::C; k += QTILE) sc[k] = gc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) {
+        const int row = tid + t * QTILE;
+        if (row < nvalid) Op::compute(sa + row * Op::A, sb + row * Op::B, sc + row * Op::C, so + row * Op::O);
+    }
+    __syncthreads();
     const int count = nvalid * Op::O;
-    if (nvalid == QTILE && (Op::O * QTILE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+    if (nvalid == RT && dev_aligned16_or_null(dst)) {
         using v4f = float __attribute__((ext_vector_type(4)));
-        for (int k = tid; k < count / 4; k += QTILE) reinterpret_cast<v4f *>(dst)[k] = *reinterpret_cast<const v4f *>(so + 4 * k);
+        constexpr int N4 = RT * Op::O / 4;
+#pragma unroll
+        for (int k0 = 0; k0 < N4; k0 += QTILE) {
+            const int k = k0 + tid;
+            if (k0 + QTILE <= N4 || k < N4) reinterpret_cast<v4f *>(dst)[k] = *reinterpret_cast<const v4f *>(so + 4 * k);
+        }
     } else {
         for (int k = tid; k < count; k += QTILE) dst[k] = so[k];
     }
@@ -148,7 +196,8 @@ static int run_rowwise(const char *who, const float *a, const float *b, const fl
     if (n < 0 || n > ((int64_t)1 << 38)) return fail(IGX_E_SIZE, "%s: n %lld out of range", who, (long long)n);
     if (n == 0) return IGX_OK;
     if (!a || (Op::B && !b) || (Op::C && !c) || !out) return fail(IGX_E_NULL, "%s: NULL argument", who);
-    const int64_t blocks = (n + QTILE - 1) / QTILE;
+    constexpr int RT = RowwiseShape<Op>::RT;
+    const int64_t blocks = (n + RT - 1) / RT;
     hipLaunchKernelGGL((rowwise_kernel<Op>), dim3((unsigned)blocks), dim3(QTILE), 0, static_cast<hipStream_t>(stream), a,
                        b, c, out, n);
     return launch_status(who);
