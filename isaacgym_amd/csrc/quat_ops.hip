@@ -441,11 +441,34 @@ __global__ __launch_bounds__(QTILE) void multi_kernel(const RowPtrs p, int64_t n
     const int nvalid = (n - base >= QTILE) ? QTILE : (int)(n - base);
     const float *in[MAX_IN];
     float *out[MAX_OUT];
+    static_assert(MAX_IN == 5, "the register staging below names five slabs");
+    constexpr int O1 = Op::IW[0], O2 = O1 + Op::IW[1], O3 = O2 + Op::IW[2], O4 = O3 + Op::IW[3];
+    bool fast = nvalid == QTILE;
+#pragma unroll
+    for (int k = 0; k < MAX_IN; ++k)
+        if (Op::IW[k]) fast = fast && dev_aligned16_or_null(p.in[k] + base * Op::IW[k]);
     int off = 0;
+    if (fast) {  // every array's loads in flight before the first wait
+        Slab<Op::IW[0], QTILE> r0;
+        Slab<Op::IW[1], QTILE> r1;
+        Slab<Op::IW[2], QTILE> r2;
+        Slab<Op::IW[3], QTILE> r3;
+        Slab<Op::IW[4], QTILE> r4;
+        r0.load(p.in[0] + base * Op::IW[0], tid);
+        r1.load(p.in[1] + base * Op::IW[1], tid);
+        r2.load(p.in[2] + base * Op::IW[2], tid);
+        r3.load(p.in[3] + base * Op::IW[3], tid);
+        r4.load(p.in[4] + base * Op::IW[4], tid);
+        r0.store(s_in, tid);
+        r1.store(s_in + QTILE * O1, tid);
+        r2.store(s_in + QTILE * O2, tid);
+        r3.store(s_in + QTILE * O3, tid);
+        r4.store(s_in + QTILE * O4, tid);
+    }
 #pragma unroll
     for (int k = 0; k < MAX_IN; ++k) {
         in[k] = s_in + QTILE * off + tid * Op::IW[k];
-        if (Op::IW[k]) slab_load(p.in[k], s_in + QTILE * off, Op::IW[k], base, nvalid, tid);
+        if (Op::IW[k] && !fast) slab_load(p.in[k], s_in + QTILE * off, Op::IW[k], base, nvalid, tid);
         off += Op::IW[k];
     }
     off = 0;
