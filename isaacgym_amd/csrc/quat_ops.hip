@@ -443,7 +443,7 @@ __global__ __launch_bounds__(QTILE) void multi_kernel(const RowPtrs p, int64_t n
     float *out[MAX_OUT];
     static_assert(MAX_IN == 5, "the register staging below names five slabs");
     constexpr int O1 = Op::IW[0], O2 = O1 + Op::IW[1], O3 = O2 + Op::IW[2], O4 = O3 + Op::IW[3];
-    bool fast = nvalid == QTILE;
+    bool fast = nvalid == QTILE && Op::IW[1] != 0;  // a single input array has nothing to overlap with
 #pragma unroll
     for (int k = 0; k < MAX_IN; ++k)
         if (Op::IW[k]) fast = fast && dev_aligned16_or_null(p.in[k] + base * Op::IW[k]);
