@@ -133,24 +133,42 @@ __global__ __launch_bounds__(256) void noise_kernel(const igx_noise nz, const fl
     store4(out, i0, count, vec, v);
 }
 
-// Actions of the force / PD-target tasks: one lane per four consecutive actions.
+// Actions of the force / PD-target tasks: one lane per four consecutive actions; the per-action gains
+// and offsets sit in LDS when they fit (per-element reads of them through the vector memory path queue
+// behind the streaming loads).
+constexpr int ACT_LDS = 256;
+
 __global__ __launch_bounds__(256) void action_stage_kernel(const igx_action_stage s, int64_t count, bool vec, bool small)
 {
+    __shared__ float s_gain[ACT_LDS], s_off[ACT_LDS];
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= count) return;
-    float a[4];
-    load4(s.actions, i0, count, vec, a);
-    apply_noise4(s.noise, i0, count, vec, a);
+    const bool live = i0 < count;
+    const int A = s.num_actions;
+    const bool pd = s.mode == IGX_ACT_PD_TARGET;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+        load4(s.actions, i0, count, vec, a);
+        apply_noise4(s.noise, i0, count, vec, a);
+    }
+    const bool staged = A <= ACT_LDS;
+    if (staged) {
+        if ((int)threadIdx.x < A) {
+            s_gain[threadIdx.x] = s.gain[threadIdx.x];
+            s_off[threadIdx.x] = pd ? s.offset[threadIdx.x] : 0.0f;
+        }
+        __syncthreads();
+    }
+    if (!live) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[k] = clamp1(a[k], -s.clip_actions, s.clip_actions);
     if (s.actions_out) store4(s.actions_out, i0, count, vec, a);
-    const int A = s.num_actions;
     int j = small ? (int)((uint32_t)i0 % (uint32_t)A) : (int)(i0 % A);
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float g = s.gain[j];
-        t[k] = s.mode == IGX_ACT_PD_TARGET ? s.offset[j] + g * a[k] : (a[k] * g) * s.power_scale;
+        const float g = staged ? s_gain[j] : s.gain[j];
+        const float o = !pd ? 0.0f : (staged ? s_off[j] : s.offset[j]);
+        t[k] = pd ? o + g * a[k] : (a[k] * g) * s.power_scale;
         j = j + 1 == A ? 0 : j + 1;
     }
     store4(s.targets, i0, count, vec, t);
