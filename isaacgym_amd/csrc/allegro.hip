@@ -75,9 +75,11 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
     }
     // the tile's slab of previous targets -> LDS (the reset below may overwrite rows)
     const int count = nvalid * AD;
+    v4f act[AD / 4];  // the actions are requested in the same round trip
     if (nvalid == WAVE) {
         v4f r[AD / 4];
         load_chunks<WAVE * AD / 4>(b.prev_targets + base * AD, r, lane);
+        load_chunks<WAVE * AD / 4>(b.actions + base * AD, act, lane);
 #pragma unroll
         for (int it = 0; it < AD / 4; ++it) *reinterpret_cast<v4f *>(s_prev + 4 * (lane + it * WAVE)) = r[it];
     } else {
@@ -126,8 +128,6 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
     // ---- action path over the tile's slab (chunk k: env k/4, joints 4(k%4)..)
     auto target = [&](float a, float prev, float lo, float hi) { return joint_target(p, a, prev, lo, hi); };
     if (nvalid == WAVE) {
-        v4f act[AD / 4];
-        load_chunks<WAVE * AD / 4>(b.actions + base * AD, act, lane);
 #pragma unroll
         for (int it = 0; it < AD / 4; ++it) {
             const int k = lane + it * WAVE;

@@ -87,12 +87,15 @@ __global__ __launch_bounds__(WAVE) void shadow_pre_kernel(const igx_shadow_param
         rst = b.reset[e];
         rg = b.reset_goal[e];
     }
-    // the tile's slabs of targets -> LDS
+    // the tile's slabs of targets -> LDS; the actions are requested in the same round trip
     const int count = nvalid * SD;
+    float r_act[SA];
     if (nvalid == WAVE) {
         v4f rp[SD / 4], rc[SD / 4];
         load_chunks<WAVE * SD / 4>(b.prev_targets + base * SD, rp, lane);
         load_chunks<WAVE * SD / 4>(b.cur_targets + base * SD, rc, lane);
+#pragma unroll
+        for (int it = 0; it < SA; ++it) r_act[it] = ld_stream(b.actions + base * SA + lane + it * WAVE);
 #pragma unroll
         for (int it = 0; it < SD / 4; ++it) {
             *reinterpret_cast<v4f *>(s_prev + 4 * (lane + it * WAVE)) = rp[it];
@@ -142,11 +145,22 @@ __global__ __launch_bounds__(WAVE) void shadow_pre_kernel(const igx_shadow_param
     wave_sync();
 
     // ---- action path (:684-697): actuated joints only; the others keep their targets
-    for (int i = lane; i < nvalid * SA; i += WAVE) {
-        const int env = i / SA, a = i - env * SA, j = s_idx[a];
-        const float c = joint_target(p, b.actions[base * SA + i], s_prev[env * SD + j], s_lim[j], s_lim[SD + j]);
-        s_cur[env * SD + j] = c;
-        s_prev[env * SD + j] = c;
+    if (nvalid == WAVE) {
+#pragma unroll
+        for (int it = 0; it < SA; ++it) {
+            const int i = lane + it * WAVE;
+            const int env = i / SA, a = i - env * SA, j = s_idx[a];
+            const float c = joint_target(p, r_act[it], s_prev[env * SD + j], s_lim[j], s_lim[SD + j]);
+            s_cur[env * SD + j] = c;
+            s_prev[env * SD + j] = c;
+        }
+    } else {
+        for (int i = lane; i < nvalid * SA; i += WAVE) {
+            const int env = i / SA, a = i - env * SA, j = s_idx[a];
+            const float c = joint_target(p, b.actions[base * SA + i], s_prev[env * SD + j], s_lim[j], s_lim[SD + j]);
+            s_cur[env * SD + j] = c;
+            s_prev[env * SD + j] = c;
+        }
     }
     wave_sync();
     if (nvalid == WAVE) {
