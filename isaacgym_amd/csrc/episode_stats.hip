@@ -25,26 +25,62 @@ struct EpisodeRecord {
 };
 static_assert(sizeof(EpisodeRecord) == IGX_EPISODE_RECORD_BYTES, "record size is part of the ABI");
 
-__global__ __launch_bounds__(256) void episode_step_kernel(const igx_episode_buffers b, int64_t n, EpisodeRecord *ws)
+// one environment's update: rlgames_utils.py:151-211 / common_agent.py:284-296 restated per element
+__device__ __forceinline__ void episode_update(int64_t done, float rew, float &cr, float &cl, float &dr, float &dl,
+                                               unsigned long long &cnt)
 {
+    const float not_done = 1.0f - (float)(done != 0 ? 1 : 0);
+    cr = cr + rew;
+    cl = cl + 1.0f;
+    if (not_done == 0.0f) {
+        dr += cr;
+        dl += cl;
+        cnt += 1;
+    }
+    cr *= not_done;
+    cl *= not_done;
+}
+
+// Four consecutive environments per lane (16-byte loads and stores when `vec`), one record per block of 1024.
+__global__ __launch_bounds__(256) void episode_step_kernel(const igx_episode_buffers b, int64_t n, EpisodeRecord *ws, bool vec)
+{
+    using v2l = long long __attribute__((ext_vector_type(2)));
     __shared__ unsigned long long s_cnt[4];
     __shared__ double s_rew[4], s_len[4];
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float dr = 0.0f, dl = 0.0f;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     unsigned long long cnt = 0;
-    if (e < n) {
-        const float not_done = 1.0f - (float)(ld_stream(b.done + e) != 0 ? 1 : 0);
-        float cr = ld_stream(b.current_rewards + e) + ld_stream(b.rew + e);
-        float cl = ld_stream(b.current_lengths + e) + 1.0f;
-        if (not_done == 0.0f) {
-            dr = cr;
-            dl = cl;
-            cnt = 1;
+    double r = 0.0, l = 0.0;  // finished episodes of this lane's environments, widened one by one
+    if (vec && e0 + 3 < n) {
+        const v2l d0 = ld_stream(reinterpret_cast<const v2l *>(b.done + e0));
+        const v2l d1 = ld_stream(reinterpret_cast<const v2l *>(b.done + e0) + 1);
+        const v4f rw = ld_stream(reinterpret_cast<const v4f *>(b.rew + e0));
+        const v4f cr = ld_stream(reinterpret_cast<const v4f *>(b.current_rewards + e0));
+        const v4f cl = ld_stream(reinterpret_cast<const v4f *>(b.current_lengths + e0));
+        const long long d[4] = {d0.x, d0.y, d1.x, d1.y};
+        const float w[4] = {rw.x, rw.y, rw.z, rw.w};
+        float c[4] = {cr.x, cr.y, cr.z, cr.w}, len[4] = {cl.x, cl.y, cl.z, cl.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float dr = 0.0f, dl = 0.0f;
+            episode_update(d[k], w[k], c[k], len[k], dr, dl, cnt);
+            r += (double)dr;
+            l += (double)dl;
         }
-        st_stream(b.current_rewards + e, cr * not_done);
-        st_stream(b.current_lengths + e, cl * not_done);
+        st_stream(reinterpret_cast<v4f *>(b.current_rewards + e0), v4f{c[0], c[1], c[2], c[3]});
+        st_stream(reinterpret_cast<v4f *>(b.current_lengths + e0), v4f{len[0], len[1], len[2], len[3]});
+    } else {
+        for (int k = 0; k < 4; ++k) {
+            const int64_t e = e0 + k;
+            if (e < n) {
+                float c = b.current_rewards[e], len = b.current_lengths[e], dr = 0.0f, dl = 0.0f;
+                episode_update(b.done[e], b.rew[e], c, len, dr, dl, cnt);
+                r += (double)dr;
+                l += (double)dl;
+                b.current_rewards[e] = c;
+                b.current_lengths[e] = len;
+            }
+        }
     }
-    double r = (double)dr, l = (double)dl;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_xor(r, off);
@@ -105,10 +141,11 @@ extern "C" int igx_episode_stats_step(const igx_episode_buffers *b, int64_t n_en
     if (!b->rew || !b->done || !b->current_rewards || !b->current_lengths || !b->workspace)
         return fail(IGX_E_NULL, "igx_episode_stats_step: a buffer is NULL");
     if (!aligned16(b->workspace)) return fail(IGX_E_ALIGN, "igx_episode_stats_step: workspace must be 16-byte aligned");
-    const int64_t blocks = (n_envs + 255) / 256;
+    const int64_t blocks = (n_envs + 1023) / 1024;  // a quarter of the records the workspace has room for
     hipStream_t s = static_cast<hipStream_t>(stream);
     EpisodeRecord *ws = static_cast<EpisodeRecord *>(b->workspace);
-    hipLaunchKernelGGL(episode_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *b, n_envs, ws);
+    const bool vec = aligned16(b->rew) && aligned16(b->done) && aligned16(b->current_rewards) && aligned16(b->current_lengths);
+    hipLaunchKernelGGL(episode_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *b, n_envs, ws, vec);
     int rc = launch_status("igx_episode_stats_step");
     if (rc != IGX_OK) return rc;
     hipLaunchKernelGGL(episode_reduce_kernel, dim3(1), dim3(1024), 0, s, ws, blocks);
