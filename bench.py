@@ -4,7 +4,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch one rank per GPU with torch.distributed.run; environments
+For N > 1 there is one rank per GPU: either torch.distributed.run started them
+(WORLD_SIZE is set), or this process starts N fresh children itself before it
+touches the GPU, waits for them and relays rank 0's JSON line.  Environments
 shard into independent contiguous blocks (weak scaling: 2^20 envs per GPU), so
 the step path has no collective - RCCL is used for the barrier and for the
 MAX-over-ranks of the timed region only.
@@ -48,6 +50,8 @@ def parse():
                     help="also run the episode-statistics kernel every step (inside the timed region) and "
                          "all-gather the totals over the ranks afterwards")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample size in steps (0 = auto)")
+    ap.add_argument("--spawn-timeout", type=float, default=900.0,
+                    help="seconds the self-started ranks of an N > 1 run may take")
     return ap.parse_args()
 
 
@@ -89,8 +93,21 @@ def load_traffic():
         return None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (rank -> device as the reference's rlgames_utils.py:91-112), relay rank 0's output."""
+    from isaacgym_amd.launch import spawn_ranks
+    rc, out = spawn_ranks([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                          timeout=args.spawn_timeout)
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # nothing above has touched the GPU
     import torch
     import torch.distributed as dist
     from isaacgym_amd import ops, synthetic
@@ -99,9 +116,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev_index = local_rank if args.all_ranks_on_device < 0 else args.all_ranks_on_device
     torch.cuda.set_device(dev_index)
@@ -130,10 +144,19 @@ def main():
         from isaacgym_amd.episode_stats import EpisodeStats
         es = EpisodeStats(n, dev)
 
-    def run(k0, k):
+    step_events = []  # with --episode-stats: one event pair per step around the step kernel alone
+
+    def run(k0, k, timed=False):
         for i in range(k0, k0 + k):
             p.rng_offset = i
-            step(p, sets[i % NUM_INPUT_SETS], n)
+            if es is not None and timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                step(p, sets[i % NUM_INPUT_SETS], n)
+                e1.record()
+                step_events.append((e0, e1))
+            else:
+                step(p, sets[i % NUM_INPUT_SETS], n)
             if es is not None:
                 es.step(sets[0]["rew"], sets[0]["reset"])
 
@@ -148,11 +171,14 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(args.warmup, args.steps)
+    run(args.warmup, args.steps, timed=True)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per launch on the launch stream
+    if step_events:  # the episode kernels sit between ev0 and ev1: price the step kernel by its own pairs
+        kernel_ms = sum(a.elapsed_time(b) for a, b in step_events) / len(step_events)
+    else:
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per launch on the launch stream
 
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)

@@ -62,6 +62,12 @@ def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _host_backend(group=None):
+    """True when the group's backend moves host memory only (gloo has no all_gather_into_tensor for
+    device tensors): device records then travel through the host."""
+    return dist.get_backend(group) == "gloo"
+
+
 def gather_records(record, group=None):
     """All-gather one fixed-size record per rank: 1-D tensor [R] -> [world, R], rank order."""
     record = record.contiguous()
@@ -69,9 +75,12 @@ def gather_records(record, group=None):
     if w == 1:
         return record.unsqueeze(0).clone()
     flat = record.reshape(-1)
-    out = torch.empty(w * flat.numel(), dtype=record.dtype, device=record.device)
+    dev = record.device
+    if dev.type != "cpu" and _host_backend(group):
+        flat = flat.cpu()
+    out = torch.empty(w * flat.numel(), dtype=record.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)  # concatenation along dim 0, rank order
-    return out.view((w,) + tuple(record.shape))
+    return out.to(dev).view((w,) + tuple(record.shape))
 
 
 def all_gather_rows(rows, group=None):
@@ -80,9 +89,12 @@ def all_gather_rows(rows, group=None):
     w = world_size(group)
     if w == 1:
         return rows
+    dev = rows.device
+    if dev.type != "cpu" and _host_backend(group):
+        rows = rows.cpu()
     out = torch.empty((w * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
     dist.all_gather_into_tensor(out, rows, group=group)
-    return out
+    return out.to(dev)
 
 
 def max_over_ranks(value, device, group=None):
