@@ -348,6 +348,19 @@ int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffe
 int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
                              int64_t n_envs, igx_stream_t stream);
 
+/* igx_allegro_post_physics for callers that cannot allocate device memory and bring no workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No
+ * counterpart in the reference.  b->workspace is ignored: the per-tile records of the reduction
+ * live in a file-scope device array of IGX_ALLEGRO_STATIC_SCRATCH_BYTES inside the library, one
+ * copy per GPU, held until the process ends.  n_envs above IGX_ALLEGRO_STATIC_MAX_ENVS is
+ * IGX_E_SIZE.  The call allocates and frees nothing and gives the same results as
+ * igx_allegro_post_physics.  Every call on one GPU uses that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race; calls on one stream, or ordered by events, do not. */
+#define IGX_ALLEGRO_STATIC_MAX_ENVS ((int64_t)1 << 21)
+#define IGX_ALLEGRO_STATIC_SCRATCH_BYTES (16 * ((1 << 21) / 16 + 1)) /* = IGX_ALLEGRO_WORKSPACE_BYTES(max) */
+int igx_allegro_post_physics_static(const igx_allegro_params *p, const igx_allegro_buffers *b,
+                                    int64_t n_envs, igx_stream_t stream);
+
 /* Environment-sharded form of igx_allegro_post_physics (one shard per GPU).
  * compute_hand_reward's consecutive_successes (tasks/allegro_hand.py:714-719)
  * averages over ALL environments, so a shard stops after leaving its 16-byte

@@ -265,3 +265,7 @@ def make_buffers(cls, arrays, ptr_of):
         a = arrays.get(n)
         setattr(b, n, None if a is None else ptr_of(a))
     return b
+
+# igx_allegro_post_physics_static: the library-owned reduction scratch
+IGX_ALLEGRO_STATIC_MAX_ENVS = 1 << 21
+IGX_ALLEGRO_STATIC_SCRATCH_BYTES = 16 * ((1 << 21) // 16 + 1)

@@ -30,6 +30,7 @@ SYMBOLS = {
     "igx_humanoid_step": _STEP_SIG,
     "igx_allegro_pre_physics": _STEP_SIG,
     "igx_allegro_post_physics": _STEP_SIG,
+    "igx_allegro_post_physics_static": _STEP_SIG,
     "igx_allegro_post_physics_shard": _STEP_SIG,
     "igx_allegro_finalize_shards": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "igx_shadow_pre_physics": _STEP_SIG,

@@ -17,6 +17,8 @@
 //
 // Reference: IsaacGymEnvs/isaacgymenvs/tasks/allegro_hand.py:586-615, :506-584,
 // :722-732 (pre) and :627-632, :406-504, :663-719 (post).
+#include <atomic>
+
 #include "igx_device.hpp"
 #include "igx_host.hpp"
 #include "igx_hand.hpp"
@@ -389,6 +391,58 @@ extern "C" int igx_allegro_post_physics(const igx_allegro_params *p, const igx_a
     int rc = check_allegro(p, b, n, true, "igx_allegro_post_physics");
     if (rc != IGX_OK || n == 0) return rc;
     return allegro_post_launch(p, b, n, true, stream);
+}
+
+// ---- the variant for callers that may not allocate and bring no workspace ------------------
+// The per-tile records of the reduction live in this file-scope array instead of b->workspace.
+// One copy per GPU, held until the process ends; its address on a device is looked up once with
+// that device current, and only that address (never the array's name) is handed to kernels.
+static __device__ __align__(256) unsigned char scratch[IGX_ALLEGRO_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_scratch_ptr[kMaxDevices];
+
+// device address of `scratch` on the current device (no allocation; thread-safe: every thread that
+// races here computes the same address)
+int scratch_address(void **out, const char *who)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "%s: hipGetDevice: %s", who, hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail(IGX_E_NODEVICE, "%s: device index %d not supported", who, dev);
+    void *ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(e != hipSuccess ? (int)e : IGX_E_NODEVICE, "%s: hipGetSymbolAddress(scratch): %s", who,
+                        hipGetErrorString(e));
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    *out = ptr;
+    return IGX_OK;
+}
+}  // namespace
+
+extern "C" int igx_allegro_post_physics_static(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
+                                               igx_stream_t stream)
+{
+    const char *who = "igx_allegro_post_physics_static";
+    if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
+    if (n > IGX_ALLEGRO_STATIC_MAX_ENVS)
+        return fail(IGX_E_SIZE, "%s: n_envs %lld exceeds IGX_ALLEGRO_STATIC_MAX_ENVS (%lld); use igx_allegro_post_physics "
+                    "with a caller-provided workspace", who, (long long)n, (long long)IGX_ALLEGRO_STATIC_MAX_ENVS);
+    igx_allegro_buffers bb = *b;
+    bb.workspace = nullptr;
+    if (n > 0) {
+        int rc = scratch_address(&bb.workspace, who);
+        if (rc != IGX_OK) return rc;
+    }
+    int rc = check_allegro(p, &bb, n, true, who);
+    if (rc != IGX_OK || n == 0) return rc;
+    // every tile writes its record and the reduction writes record 0 before anything reads them:
+    // nothing of the previous call's contents survives into this one, so nothing is cleared
+    return allegro_post_launch(p, &bb, n, true, stream);
 }
 
 extern "C" int igx_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,

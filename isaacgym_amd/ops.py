@@ -46,6 +46,12 @@ def allegro_post_physics(params, tensors, n_envs):
     _lib.call_step("igx_allegro_post_physics", params, _abi.AllegroBuffers, tensors, n_envs)
 
 
+def allegro_post_physics_static(params, tensors, n_envs):
+    """igx_allegro_post_physics with the reduction records in the library's own file-scope device
+    array: allocates nothing and ignores tensors['workspace'] (n_envs <= IGX_ALLEGRO_STATIC_MAX_ENVS)."""
+    _lib.call_step("igx_allegro_post_physics_static", params, _abi.AllegroBuffers, tensors, n_envs)
+
+
 # ---- AMP motion library / HumanoidAMP ---------------------------------------
 _TABLE_DTYPES = dict(motion_length=torch.float64, motion_dt=torch.float64, motion_num_frames=torch.int64,
                      frame_offset=torch.int64)
