@@ -106,42 +106,42 @@ __device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx
     }
 }
 
-// What lane i computes for environment e from its root row (13 registers) and
-// its LDS observation row.  Returns up_vec / heading_vec for the drain.
-template <int D, int S, bool HUM, int T, bool IMIT>
-__device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco_buffers &b, const igx_imitate_args &im, int64_t e,
-                                        const float (&rr)[13], int64_t prog, int64_t rst, int64_t rnd, float pot,
-                                        float *row, const float *s_lim, f3 &up_vec, f3 &heading_vec)
+// What lane i computes for environment e, in two parts.  Part A needs only the root row and the
+// per-environment scalars, so it runs while the tile's wide streams (dof state, sensors, actions)
+// are still arriving; part B needs the staged observation row.
+struct EnvA {
+    float c[12];          // observation columns 0..11
+    f3 up_vec, heading_vec;
+    float pot, prev_pot, pos_z, lin_x;
+    int64_t prog, rst;
+};
+
+template <bool HUM>
+__device__ __forceinline__ void per_env_a(const igx_loco_params &p, const igx_loco_buffers &b, int64_t e,
+                                          const float (&rr)[13], int64_t prog, int64_t rst, float pot, EnvA &a)
 {
-    using L = LocoLayout<D, S, HUM, T>;
-    constexpr int NOBS = L::NOBS;
     const f3 pos{rr[0], rr[1], rr[2]};
     const f4 rot{rr[3], rr[4], rr[5], rr[6]};
     const f3 lin{rr[7], rr[8], rr[9]};
     const f3 ang{rr[10], rr[11], rr[12]};
 
+    // a flagged environment (reset_idx) restarts from potentials = -|targets - initial root|/dt, which
+    // only the reward reads (as prev_potentials): part B fetches the initial root row, so that no
+    // memory access sits between the arrival of the root rows and this math
     prog += 1;
-    if (b.randomize) st_stream(b.randomize + e, rnd + 1);
-
-    if (rst != 0) {  // reset_idx, per-env scalars (the joints were re-drawn by reset_joints)
-        const float *ir = b.initial_root_states + e * 13;
-        const f3 tt{p.targets[0] - ir[0], p.targets[1] - ir[1], 0.0f};
-        pot = -norm3(tt) / p.dt;
-        prog = 0;
-        rst = 0;
-    }
+    if (rst != 0) prog = 0;
 
     // compute_*_observations
     const f3 to_target{p.targets[0] - pos.x, p.targets[1] - pos.y, 0.0f};
-    const float prev_pot = pot;
-    pot = -norm3(to_target) / p.dt;
+    a.prev_pot = pot;
+    a.pot = -norm3(to_target) / p.dt;
     const f3 target_dirs = normalize3(to_target);
     const f4 isr{p.inv_start_rot[0], p.inv_start_rot[1], p.inv_start_rot[2], p.inv_start_rot[3]};
     const f4 tq = quat_mul(rot, isr);
-    up_vec = quat_rotate<false>(tq, f3{p.basis_vec1[0], p.basis_vec1[1], p.basis_vec1[2]});
-    heading_vec = quat_rotate<false>(tq, f3{p.basis_vec0[0], p.basis_vec0[1], p.basis_vec0[2]});
-    const float up_proj = up_vec.z;
-    const float heading_proj = dot3(heading_vec, target_dirs);
+    a.up_vec = quat_rotate<false>(tq, f3{p.basis_vec1[0], p.basis_vec1[1], p.basis_vec1[2]});
+    a.heading_vec = quat_rotate<false>(tq, f3{p.basis_vec0[0], p.basis_vec0[1], p.basis_vec0[2]});
+    const float up_proj = a.up_vec.z;
+    const float heading_proj = dot3(a.heading_vec, target_dirs);
     const f3 vel_loc = quat_rotate<true>(tq, lin);
     f3 angvel_loc = quat_rotate<true>(tq, ang);
     float roll, yaw;
@@ -155,9 +155,35 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
         angvel_loc.y *= p.angular_velocity_scale;
         angvel_loc.z *= p.angular_velocity_scale;
     }
-    *reinterpret_cast<v4f *>(row + 0) = v4f{pos.z, vel_loc.x, vel_loc.y, vel_loc.z};
-    *reinterpret_cast<v4f *>(row + 4) = v4f{angvel_loc.x, angvel_loc.y, angvel_loc.z, yaw};
-    *reinterpret_cast<v4f *>(row + 8) = v4f{roll, angle_to_target, up_proj, heading_proj};
+    a.c[0] = pos.z; a.c[1] = vel_loc.x; a.c[2] = vel_loc.y; a.c[3] = vel_loc.z;
+    a.c[4] = angvel_loc.x; a.c[5] = angvel_loc.y; a.c[6] = angvel_loc.z; a.c[7] = yaw;
+    a.c[8] = roll; a.c[9] = angle_to_target; a.c[10] = up_proj; a.c[11] = heading_proj;
+    a.pos_z = pos.z;
+    a.lin_x = lin.x;
+    a.prog = prog;
+    a.rst = rst;
+}
+
+template <int D, int S, bool HUM, int T, bool IMIT>
+__device__ __forceinline__ void per_env_b(const igx_loco_params &p, const igx_loco_buffers &b, const igx_imitate_args &im, int64_t e,
+                                          const EnvA &a, int64_t rnd, float *row, const float *s_lim)
+{
+    using L = LocoLayout<D, S, HUM, T>;
+    constexpr int NOBS = L::NOBS;
+    int64_t prog = a.prog, rst = a.rst;
+    float prev_pot = a.prev_pot;
+    const float pot = a.pot;
+    if (rst != 0) {  // reset_idx, per-env scalars (the joints were re-drawn by reset_joints)
+        const float *ir = b.initial_root_states + e * 13;
+        const f3 tt{p.targets[0] - ir[0], p.targets[1] - ir[1], 0.0f};
+        prev_pot = -norm3(tt) / p.dt;
+        rst = 0;
+    }
+    const float up_proj = a.c[10], heading_proj = a.c[11];
+    if (b.randomize) st_stream(b.randomize + e, rnd + 1);
+    *reinterpret_cast<v4f *>(row + 0) = v4f{a.c[0], a.c[1], a.c[2], a.c[3]};
+    *reinterpret_cast<v4f *>(row + 4) = v4f{a.c[4], a.c[5], a.c[6], a.c[7]};
+    *reinterpret_cast<v4f *>(row + 8) = v4f{a.c[8], a.c[9], a.c[10], a.c[11]};
 
     // compute_*_reward, from this environment's own observation row
     float act[D], dpos[D], dvel[D], tmp[D];
@@ -213,7 +239,7 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
         total = progress_reward + 2.0f + up_reward + heading_reward - p.actions_cost_scale * actions_cost -
                 p.energy_cost_scale * electricity_cost - dof_at_limit_cost;
     }
-    if (pos.z < p.termination_height) {
+    if (a.pos_z < p.termination_height) {
         total = IMIT ? (float)im.death_cost : p.death_cost;
         rst = 1;
     }
@@ -224,7 +250,7 @@ __device__ __forceinline__ void per_env(const igx_loco_params &p, const igx_loco
     st_stream(b.rew + e, total);
     st_stream(b.reset + e, rst);
     st_stream(b.progress + e, prog);
-    if (b.true_objective) st_stream(b.true_objective + e, lin.x);
+    if (b.true_objective) st_stream(b.true_objective + e, a.lin_x);
     if (!IMIT && b.time_outs) b.time_outs[e] = ((float)prog >= p.max_episode_length_m1 && rst != 0) ? 1 : 0;
 }
 
@@ -237,26 +263,137 @@ struct TileIn {
     v4f r_root[L::IT_ROOT], r_dof[L::IT_DOF], r_sens[L::IT_SENS], r_act[L::IT_ACT], r_force[HUM ? L::IT_ACT : 1];
 };
 
-template <int D, int S, bool HUM, int T>
-__device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t base, int64_t n, int lane, TileIn<D, S, HUM, T> &t)
+template <int D, int S, bool HUM, int T, bool FULL>
+__device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t base, int nvalid, int lane, TileIn<D, S, HUM, T> &t)
 {
     using L = LocoLayout<D, S, HUM, T>;
-    constexpr int TILE = L::TILE;
-    const int nvalid = (n - base >= TILE) ? TILE : (int)(n - base);
     // branch-free so that every load of the tile is issued before the first wait: lanes
     // without an environment re-read the tile's first one, a missing randomize buffer
     // re-reads progress (both results are never used)
+    // order: what the first part of the per-environment math needs (root rows, flags, potentials)
+    // comes first - loads return in order, and that math runs while the rest is still arriving
     const int64_t e = base + (lane < nvalid ? lane : 0);
+    if constexpr (FULL) load_chunks<L::ROOT4>(b.root_states + base * 13, t.r_root, lane);
     t.prog = ld_stream(b.progress + e);
     t.rst = ld_stream(b.reset + e);
     t.pot = ld_stream(b.potentials + e);
+    // the instruction scheduler may not move the wide loads below ahead of these: the hardware
+    // returns loads in issue order
+    __builtin_amdgcn_sched_barrier(0);
     t.rnd = ld_stream((b.randomize ? b.randomize : b.progress) + e);
-    if (nvalid == TILE) {
-        load_chunks<L::ROOT4>(b.root_states + base * 13, t.r_root, lane);
+    if constexpr (FULL) {
         load_chunks<L::DOF4>(b.dof_state + base * (2 * D), t.r_dof, lane);
         load_chunks<L::SENS4>(b.sensors + base * S, t.r_sens, lane);
         load_chunks<L::ACT4>(b.actions + base * D, t.r_act, lane);
         if constexpr (HUM) load_chunks<L::ACT4>(b.dof_force + base * D, t.r_force, lane);
+    }
+}
+
+// One tile, start to finish.  FULL (all T environments present) and the one partial tile at the end
+// of a batch are separate instantiations, so that the full tile is straight-line code: every load is
+// unconditional, and the waits the compiler places are exactly "the loads this instruction needs"
+// (a load issued under a condition would, where the paths merge, turn every later wait into "nearly all").
+template <int D, int S, bool HUM, int T, bool IMIT, bool FULL>
+__device__ __forceinline__ void loco_tile(const igx_loco_params &p, const igx_loco_buffers &b, const igx_imitate_args &im,
+                                          int64_t base, int nvalid_in, int lane, float lim, float effort, float *s_tile,
+                                          float *s_lim)
+{
+    using L = LocoLayout<D, S, HUM, T>;
+    constexpr int NOBS = L::NOBS;
+    constexpr int TILE = L::TILE;
+    const int nvalid = FULL ? TILE : nvalid_in;
+    const bool live = lane < nvalid;
+    const int64_t e = base + lane;
+
+    // ---- load: everything the tile reads, issued back to back
+    TileIn<D, S, HUM, T> in;
+    load_tile<D, S, HUM, T, FULL>(b, base, nvalid, lane, in);
+
+    if (lane < 2 * D) s_lim[lane] = lim;
+    if (HUM && lane < D) s_lim[2 * D + lane] = effort / p.max_motor_effort;
+    const int64_t prog = in.prog, rst = in.rst, rnd = in.rnd;
+    const float pot = in.pot;
+
+    // ---- root: transpose the 13-float rows through the (still empty) tile
+    if constexpr (FULL) {
+#pragma unroll
+        for (int it = 0; it < L::IT_ROOT; ++it) {
+            const int k = lane + it * WAVE;
+            if ((it + 1) * WAVE <= L::ROOT4 || k < L::ROOT4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = in.r_root[it];
+        }
+    } else {
+        for (int i = lane; i < nvalid * 13; i += WAVE) s_tile[i] = b.root_states[base * 13 + i];
+    }
+    wave_sync();
+    float rr[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) rr[i] = s_tile[(lane & (TILE - 1)) * 13 + i];  // lanes >= nvalid read stale LDS, never used
+    wave_sync();
+
+    // ---- per-env math, part A: everything that needs only the root row, while the wide
+    // streams of the tile are still in flight
+    EnvA ea;
+    if (live) per_env_a<HUM>(p, b, e, rr, prog, rst, pot, ea);
+
+    // ---- stage: pass-through columns into the observation rows
+    if constexpr (FULL) {
+        stage_dof_state<D, NOBS, L::C_POS, L::C_VEL, TILE>(in.r_dof, s_tile, s_lim, p.dof_vel_scale, lane);
+        stage_rows<S, L::C_SENS, NOBS, true, TILE>(in.r_sens, s_tile, p.contact_force_scale, lane);
+        stage_rows<D, L::C_ACT, NOBS, false, TILE>(in.r_act, s_tile, 1.0f, lane);
+        if constexpr (HUM) stage_rows<D, L::C_FORCE, NOBS, true, TILE>(in.r_force, s_tile, p.contact_force_scale, lane);
+    } else {  // plain scalar staging
+        for (int i = lane; i < nvalid * D; i += WAVE) {
+            const int env = i / D, j = i - env * D;
+            const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * D + i];
+            s_tile[env * NOBS + L::C_POS + j] = unscale(pv.x, s_lim[j], s_lim[D + j]);
+            s_tile[env * NOBS + L::C_VEL + j] = pv.y * p.dof_vel_scale;
+            s_tile[env * NOBS + L::C_ACT + j] = b.actions[base * D + i];
+            if constexpr (HUM) s_tile[env * NOBS + L::C_FORCE + j] = b.dof_force[base * D + i] * p.contact_force_scale;
+        }
+        for (int i = lane; i < nvalid * S; i += WAVE) {
+            const int env = i / S, c = i - env * S;
+            s_tile[env * NOBS + L::C_SENS + c] = b.sensors[base * S + i] * p.contact_force_scale;
+        }
+    }
+    wave_sync();
+
+    // ---- reset: re-draw the joints of flagged environments (rare)
+    const uint64_t reset_mask = __ballot(live && rst != 0);
+    if (reset_mask) {
+        reset_joints<D, S, HUM, T>(p, b, base, lane, reset_mask, s_tile, s_lim);
+        wave_sync();
+    }
+
+    // ---- per-env math, part B: the computed columns into the row, reward from the row
+    if (live) per_env_b<D, S, HUM, T, IMIT>(p, b, im, e, ea, rnd, s_tile + lane * NOBS, s_lim);
+    const f3 up_vec = ea.up_vec, heading_vec = ea.heading_vec;  // lanes without an environment: never stored
+    wave_sync();
+
+    // ---- drain: finished rows out as whole lines
+    drain_rows<NOBS, TILE>(b.obs + base * NOBS, s_tile, nvalid, lane);
+    if (!IMIT && b.obs_clamped)  // the copy VecTask.step hands to the learner
+        drain_rows_clamped<NOBS, TILE>(b.obs_clamped + base * NOBS, s_tile, nvalid, lane, p.clip_obs);
+    wave_sync();
+    // up / heading vectors: transpose through the tile's first 384 floats
+    constexpr int V3 = 3 * TILE;  // floats per vector array of a tile
+    if (lane < TILE) {
+        s_tile[lane * 3 + 0] = up_vec.x; s_tile[lane * 3 + 1] = up_vec.y; s_tile[lane * 3 + 2] = up_vec.z;
+        s_tile[V3 + lane * 3 + 0] = heading_vec.x;
+        s_tile[V3 + lane * 3 + 1] = heading_vec.y;
+        s_tile[V3 + lane * 3 + 2] = heading_vec.z;
+    }
+    wave_sync();
+    if constexpr (FULL) {
+        if (lane < V3 / 4) {
+            st_stream(reinterpret_cast<v4f *>(b.up_vec + base * 3) + lane, *reinterpret_cast<const v4f *>(s_tile + 4 * lane));
+            st_stream(reinterpret_cast<v4f *>(b.heading_vec + base * 3) + lane,
+                      *reinterpret_cast<const v4f *>(s_tile + V3 + 4 * lane));
+        }
+    } else {
+        for (int i = lane; i < nvalid * 3; i += WAVE) {
+            b.up_vec[base * 3 + i] = s_tile[i];
+            b.heading_vec[base * 3 + i] = s_tile[V3 + i];
+        }
     }
 }
 
@@ -273,7 +410,8 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
     // per-dof constants: [0,D) lower limit, [D,2D) upper limit, [2D,3D) motor effort ratio
     __shared__ __align__(16) float s_lim[(3 * D + 4) & ~3];
     const int lane = threadIdx.x;
-    const int64_t base0 = (int64_t)blockIdx.x * TILE;
+    const int64_t base = (int64_t)blockIdx.x * TILE;  // one tile per wave: several tiles per wave with
+                                                      // next-tile prefetch measured 14-18 us slower
 
     // per-dof constants picked out of the (scalar) kernel arguments by a select chain: a
     // lane-indexed read of the argument block would be a vector memory load that the
@@ -285,127 +423,10 @@ __global__ __launch_bounds__(WAVE) void loco_step_kernel(const igx_loco_params p
         lim = lane == D + j ? p.dof_limits_upper[j] : lim;
         if (HUM) effort = lane == j ? p.motor_efforts[j] : effort;
     }
-
-    // ---- load: everything the first tile reads, issued back to back
-    TileIn<D, S, HUM, T> in;
-    load_tile<D, S, HUM, T>(b, base0, n, lane, in);
-
-    if (lane < 2 * D) s_lim[lane] = lim;
-    if (HUM && lane < D) s_lim[2 * D + lane] = effort / p.max_motor_effort;
-
-    {  // one tile per wave: several tiles per wave with next-tile prefetch measured 14-18 us slower
-        const int64_t base = base0;
-        const int nvalid = (n - base >= TILE) ? TILE : (int)(n - base);
-        const bool full = nvalid == TILE;
-        const bool live = lane < nvalid;
-        const int64_t e = base + lane;
-        const int64_t prog = in.prog, rst = in.rst, rnd = in.rnd;
-        const float pot = in.pot;
-
-        // ---- root: transpose the 13-float rows through the (still empty) tile
-        if (full) {
-#pragma unroll
-            for (int it = 0; it < L::IT_ROOT; ++it) {
-                const int k = lane + it * WAVE;
-                if ((it + 1) * WAVE <= L::ROOT4 || k < L::ROOT4) *reinterpret_cast<v4f *>(s_tile + 4 * k) = in.r_root[it];
-            }
-        } else {
-            for (int i = lane; i < nvalid * 13; i += WAVE) s_tile[i] = b.root_states[base * 13 + i];
-        }
-        wave_sync();
-        float rr[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) rr[i] = s_tile[(lane & (TILE - 1)) * 13 + i];  // lanes >= nvalid read stale LDS, never used
-        wave_sync();
-
-        // ---- stage: pass-through columns into the observation rows
-        if (full) {
-            stage_dof_state<D, NOBS, L::C_POS, L::C_VEL, TILE>(in.r_dof, s_tile, s_lim, p.dof_vel_scale, lane);
-            stage_rows<S, L::C_SENS, NOBS, true, TILE>(in.r_sens, s_tile, p.contact_force_scale, lane);
-            stage_rows<D, L::C_ACT, NOBS, false, TILE>(in.r_act, s_tile, 1.0f, lane);
-            if constexpr (HUM) stage_rows<D, L::C_FORCE, NOBS, true, TILE>(in.r_force, s_tile, p.contact_force_scale, lane);
-        } else {  // the one partial tile at the end of the batch: plain scalar staging
-            for (int i = lane; i < nvalid * D; i += WAVE) {
-                const int env = i / D, j = i - env * D;
-                const v2f pv = reinterpret_cast<const v2f *>(b.dof_state)[base * D + i];
-                s_tile[env * NOBS + L::C_POS + j] = unscale(pv.x, s_lim[j], s_lim[D + j]);
-                s_tile[env * NOBS + L::C_VEL + j] = pv.y * p.dof_vel_scale;
-                s_tile[env * NOBS + L::C_ACT + j] = b.actions[base * D + i];
-                if constexpr (HUM) s_tile[env * NOBS + L::C_FORCE + j] = b.dof_force[base * D + i] * p.contact_force_scale;
-            }
-            for (int i = lane; i < nvalid * S; i += WAVE) {
-                const int env = i / S, c = i - env * S;
-                s_tile[env * NOBS + L::C_SENS + c] = b.sensors[base * S + i] * p.contact_force_scale;
-            }
-        }
-        wave_sync();
-
-        // ---- reset: re-draw the joints of flagged environments (rare)
-        const uint64_t reset_mask = __ballot(live && rst != 0);
-        if (reset_mask) {
-            reset_joints<D, S, HUM, T>(p, b, base, lane, reset_mask, s_tile, s_lim);
-            wave_sync();
-        }
-
-        // ---- per-env math
-        f3 up_vec{0, 0, 0}, heading_vec{0, 0, 0};
-        if (live) per_env<D, S, HUM, T, IMIT>(p, b, im, e, rr, prog, rst, rnd, pot, s_tile + lane * NOBS, s_lim, up_vec, heading_vec);
-        wave_sync();
-
-        // ---- drain: finished rows out as whole lines
-        if (full) {
-            constexpr int N4 = TILE * NOBS / 4;
-            v4f *o4 = reinterpret_cast<v4f *>(b.obs + base * NOBS);
-#pragma unroll
-            for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
-                const int k = lane + it * WAVE;
-                if ((it + 1) * WAVE <= N4 || k < N4) st_stream(o4 + k, *reinterpret_cast<const v4f *>(s_tile + 4 * k));
-            }
-        } else {
-            for (int i = lane; i < nvalid * NOBS; i += WAVE) b.obs[base * NOBS + i] = s_tile[i];
-        }
-        if (!IMIT && b.obs_clamped) {  // the copy VecTask.step hands to the learner
-            const float hi = p.clip_obs, lo = -p.clip_obs;
-            if (full && dev_aligned16(b.obs_clamped)) {
-                constexpr int N4 = TILE * NOBS / 4;
-                v4f *o4 = reinterpret_cast<v4f *>(b.obs_clamped + base * NOBS);
-#pragma unroll
-                for (int it = 0; it < (N4 + WAVE - 1) / WAVE; ++it) {
-                    const int k = lane + it * WAVE;
-                    if ((it + 1) * WAVE <= N4 || k < N4) {
-                        v4f v = *reinterpret_cast<const v4f *>(s_tile + 4 * k);
-                        v.x = clamp1(v.x, lo, hi); v.y = clamp1(v.y, lo, hi); v.z = clamp1(v.z, lo, hi); v.w = clamp1(v.w, lo, hi);
-                        st_stream(o4 + k, v);
-                    }
-                }
-            } else {
-                for (int i = lane; i < nvalid * NOBS; i += WAVE) b.obs_clamped[base * NOBS + i] = clamp1(s_tile[i], lo, hi);
-            }
-        }
-        wave_sync();
-        // up / heading vectors: transpose through the tile's first 384 floats
-        constexpr int V3 = 3 * TILE;  // floats per vector array of a tile
-        if (lane < TILE) {
-            s_tile[lane * 3 + 0] = up_vec.x; s_tile[lane * 3 + 1] = up_vec.y; s_tile[lane * 3 + 2] = up_vec.z;
-            s_tile[V3 + lane * 3 + 0] = heading_vec.x;
-            s_tile[V3 + lane * 3 + 1] = heading_vec.y;
-            s_tile[V3 + lane * 3 + 2] = heading_vec.z;
-        }
-        wave_sync();
-        if (full) {
-            if (lane < V3 / 4) {
-                st_stream(reinterpret_cast<v4f *>(b.up_vec + base * 3) + lane,
-                          *reinterpret_cast<const v4f *>(s_tile + 4 * lane));
-                st_stream(reinterpret_cast<v4f *>(b.heading_vec + base * 3) + lane,
-                          *reinterpret_cast<const v4f *>(s_tile + V3 + 4 * lane));
-            }
-        } else {
-            for (int i = lane; i < nvalid * 3; i += WAVE) {
-                b.up_vec[base * 3 + i] = s_tile[i];
-                b.heading_vec[base * 3 + i] = s_tile[V3 + i];
-            }
-        }
-    }
+    if (n - base >= TILE)
+        loco_tile<D, S, HUM, T, IMIT, true>(p, b, im, base, TILE, lane, lim, effort, s_tile, s_lim);
+    else
+        loco_tile<D, S, HUM, T, IMIT, false>(p, b, im, base, (int)(n - base), lane, lim, effort, s_tile, s_lim);
 }
 
 // reset_idx on an explicit id list: lane (i, j) re-draws joint j of the i-th
