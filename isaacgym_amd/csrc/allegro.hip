@@ -178,11 +178,11 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
     v4f r_dof[T * AD * 2 / 4 / WAVE], r_force[T * AD / 4 / WAVE], r_act[T * AD / 4 / WAVE];
     v4f r_goal[(T * 13 / 4 + WAVE - 1) / WAVE];
     if (live && REWARD) {
-        fl.prog = ld_stream(b.progress + e);
-        fl.rst = ld_stream(b.reset + e);
-        fl.rg = ld_stream(b.reset_goal + e);
-        fl.succ = ld_stream(b.successes + e);
-        if (b.randomize) rnd = ld_stream(b.randomize + e);
+        fl.prog = ld_narrow(b.progress + e);
+        fl.rst = ld_narrow(b.reset + e);
+        fl.rg = ld_narrow(b.reset_goal + e);
+        fl.succ = ld_narrow(b.successes + e);
+        if (b.randomize) rnd = ld_narrow(b.randomize + e);
     }
     RowWindow<T, T * NOBS> object_rows;
     object_rows.load(b.root_state_tensor, b.object_indices, e, live, full, lane, obj);
@@ -252,17 +252,17 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const igx_allegro_pa
         c[k + 7] = qd.x; c[k + 8] = qd.y; c[k + 9] = qd.z; c[k + 10] = qd.w;
 
         if (REWARD) {  // :663-719 compute_hand_reward
-            if (b.randomize) st_stream(b.randomize + e, rnd + 1);
+            if (b.randomize) st_narrow(b.randomize + e, rnd + 1);
             float act[AD], sq[AD];
             read_cols<AD, L::C_ACT, NOBS>(row, act);
 #pragma unroll
             for (int j = 0; j < AD; ++j) sq[j] = act[j] * act[j];
             const float reward = hand_reward(p, obj, goal, qd, row_sum<AD>(sq), fl, fin);
-            st_stream(b.rew + e, reward);
-            st_stream(b.reset + e, fl.rst);
-            st_stream(b.reset_goal + e, fl.rg);
-            st_stream(b.progress + e, fl.prog);
-            st_stream(b.successes + e, fl.succ);
+            st_narrow(b.rew + e, reward);
+            st_narrow(b.reset + e, fl.rst);
+            st_narrow(b.reset_goal + e, fl.rg);
+            st_narrow(b.progress + e, fl.prog);
+            st_narrow(b.successes + e, fl.succ);
             if (b.time_outs) b.time_outs[e] = ((float)fl.prog >= p.max_episode_length_m1 && fl.rst != 0) ? 1 : 0;
         }
     }

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WAVE) void amp_step_pair_kernel(const igx_amp_param
     const bool live = el < nvalid;
     const int64_t e = base + (live ? el : 0);
 
-    int64_t prog = ld_stream(b.progress + e);
+    int64_t prog = ld_narrow(b.progress + e);
     if (lane < T) s_flag[lane] = 0;
 
     constexpr int B4 = Q * BODY_ROW / 4, CF4 = T * NB * 3 / 4, ROOT4 = T * 13 / 4, DOF4 = T * 2 * ND / 4;
@@ -492,10 +492,10 @@ __global__ __launch_bounds__(WAVE) void amp_step_pair_kernel(const igx_amp_param
             int64_t terminated = 0;
             if (p.enable_early_termination && (f & 2u) && (f & 1u) && prog > 1) terminated = 1;
             const int64_t eo = base + el;
-            st_stream(b.rew + eo, 1.0f);
-            st_stream(b.reset + eo, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
-            st_stream(b.terminate + eo, terminated);
-            st_stream(b.progress + eo, prog);
+            st_narrow(b.rew + eo, 1.0f);
+            st_narrow(b.reset + eo, ((float)prog >= p.max_episode_length_m1) ? (int64_t)1 : terminated);
+            st_narrow(b.terminate + eo, terminated);
+            st_narrow(b.progress + eo, prog);
             // reset is 1 whenever the episode length is reached, so the time-out flag is that comparison
             if (b.time_outs) b.time_outs[eo] = ((float)prog >= p.max_episode_length_m1) ? 1 : 0;
         }

@@ -39,9 +39,9 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
     constexpr int BODY_ROWS = HT * HB, BODY_IT = (BODY_ROWS + WAVE - 1) / WAVE;  // one lane per (env, body) row
     v4f r_dof[(DOF4 + WAVE - 1) / WAVE], r_root[(ROOT4 + WAVE - 1) / WAVE], r_body[BODY_IT], r_act[(ACT4 + WAVE - 1) / WAVE];
     const int64_t ef = base + (lane < nvalid ? lane : 0);  // lanes 0..15 carry the per-env scalars
-    int64_t prog = ld_stream(b.progress + ef);
-    int64_t rst = ld_stream(b.reset + ef);
-    int64_t rnd = ld_stream((b.randomize ? b.randomize : b.progress) + ef);
+    int64_t prog = ld_narrow(b.progress + ef);
+    int64_t rst = ld_narrow(b.reset + ef);
+    int64_t rnd = ld_narrow((b.randomize ? b.randomize : b.progress) + ef);
     if (full) {
         load_chunks<DOF4>(b.dof_state + base * (2 * HD), r_dof, lane);
         load_chunks<ROOT4>(b.root_states + base * 13, r_root, lane);
@@ -212,10 +212,10 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
             if (z < p.termination_height) rst2 = 1;
             if (x * x + y * y > p.termination_radius_sq) rst2 = 1;
             if ((float)prog2 >= p.max_episode_length_m1) rst2 = 1;
-            st_stream(b.rew + e, (float)total);
-            st_stream(b.reset + e, rst2);
-            st_stream(b.progress + e, prog2);
-            if (b.randomize) st_stream(b.randomize + e, rnd_e + 1);
+            st_narrow(b.rew + e, (float)total);
+            st_narrow(b.reset + e, rst2);
+            st_narrow(b.progress + e, prog2);
+            if (b.randomize) st_narrow(b.randomize + e, rnd_e + 1);
             if (b.time_outs) b.time_outs[e] = ((float)prog2 >= p.max_episode_length_m1 && rst2 != 0) ? 1 : 0;
         }
     }

@@ -25,6 +25,14 @@ __device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontempora
 template <class T>
 __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
 
+// Per-environment scalars (one 4- or 8-byte element per lane: flags, potentials, rewards) take the
+// default cache policy.  Measured on MI355X: the nt forms pay off for the 16-byte-per-lane streams only;
+// on these narrow accesses they cost the Ant step 4-6 us of 102 and the Humanoid step 9 us of 181.
+template <class T>
+__device__ __forceinline__ T ld_narrow(const T *p) { return *p; }
+template <class T>
+__device__ __forceinline__ void st_narrow(T *p, T v) { *p = v; }
+
 __device__ __forceinline__ v4f ld_stream_u(const float *p)
 {
     return __builtin_nontemporal_load(reinterpret_cast<const v4f_u *>(p));

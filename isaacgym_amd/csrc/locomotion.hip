@@ -180,7 +180,7 @@ __device__ __forceinline__ void per_env_b(const igx_loco_params &p, const igx_lo
         rst = 0;
     }
     const float up_proj = a.c[10], heading_proj = a.c[11];
-    if (b.randomize) st_stream(b.randomize + e, rnd + 1);
+    if (b.randomize) st_narrow(b.randomize + e, rnd + 1);
     *reinterpret_cast<v4f *>(row + 0) = v4f{a.c[0], a.c[1], a.c[2], a.c[3]};
     *reinterpret_cast<v4f *>(row + 4) = v4f{a.c[4], a.c[5], a.c[6], a.c[7]};
     *reinterpret_cast<v4f *>(row + 8) = v4f{a.c[8], a.c[9], a.c[10], a.c[11]};
@@ -245,12 +245,12 @@ __device__ __forceinline__ void per_env_b(const igx_loco_params &p, const igx_lo
     }
     if ((float)prog >= p.max_episode_length_m1) rst = 1;
 
-    st_stream(b.potentials + e, pot);
-    st_stream(b.prev_potentials + e, prev_pot);
-    st_stream(b.rew + e, total);
-    st_stream(b.reset + e, rst);
-    st_stream(b.progress + e, prog);
-    if (b.true_objective) st_stream(b.true_objective + e, a.lin_x);
+    st_narrow(b.potentials + e, pot);
+    st_narrow(b.prev_potentials + e, prev_pot);
+    st_narrow(b.rew + e, total);
+    st_narrow(b.reset + e, rst);
+    st_narrow(b.progress + e, prog);
+    if (b.true_objective) st_narrow(b.true_objective + e, a.lin_x);
     if (!IMIT && b.time_outs) b.time_outs[e] = ((float)prog >= p.max_episode_length_m1 && rst != 0) ? 1 : 0;
 }
 
@@ -274,18 +274,19 @@ __device__ __forceinline__ void load_tile(const igx_loco_buffers &b, int64_t bas
     // comes first - loads return in order, and that math runs while the rest is still arriving
     const int64_t e = base + (lane < nvalid ? lane : 0);
     if constexpr (FULL) load_chunks<L::ROOT4>(b.root_states + base * 13, t.r_root, lane);
-    t.prog = ld_stream(b.progress + e);
-    t.rst = ld_stream(b.reset + e);
-    t.pot = ld_stream(b.potentials + e);
+    t.prog = ld_narrow(b.progress + e);
+    t.rst = ld_narrow(b.reset + e);
+    t.pot = ld_narrow(b.potentials + e);
     // the instruction scheduler may not move the wide loads below ahead of these: the hardware
     // returns loads in issue order
     __builtin_amdgcn_sched_barrier(0);
-    t.rnd = ld_stream((b.randomize ? b.randomize : b.progress) + e);
+    t.rnd = ld_narrow((b.randomize ? b.randomize : b.progress) + e);
     if constexpr (FULL) {
         load_chunks<L::DOF4>(b.dof_state + base * (2 * D), t.r_dof, lane);
-        load_chunks<L::SENS4>(b.sensors + base * S, t.r_sens, lane);
         load_chunks<L::ACT4>(b.actions + base * D, t.r_act, lane);
+        __builtin_amdgcn_sched_barrier(0);  // what the reward reads, before the pure pass-through columns
         if constexpr (HUM) load_chunks<L::ACT4>(b.dof_force + base * D, t.r_force, lane);
+        load_chunks<L::SENS4>(b.sensors + base * S, t.r_sens, lane);
     }
 }
 
@@ -335,12 +336,10 @@ __device__ __forceinline__ void loco_tile(const igx_loco_params &p, const igx_lo
     EnvA ea;
     if (live) per_env_a<HUM>(p, b, e, rr, prog, rst, pot, ea);
 
-    // ---- stage: pass-through columns into the observation rows
+    // ---- stage, first half: the columns the reward reads (joint positions / velocities, actions)
     if constexpr (FULL) {
         stage_dof_state<D, NOBS, L::C_POS, L::C_VEL, TILE>(in.r_dof, s_tile, s_lim, p.dof_vel_scale, lane);
-        stage_rows<S, L::C_SENS, NOBS, true, TILE>(in.r_sens, s_tile, p.contact_force_scale, lane);
         stage_rows<D, L::C_ACT, NOBS, false, TILE>(in.r_act, s_tile, 1.0f, lane);
-        if constexpr (HUM) stage_rows<D, L::C_FORCE, NOBS, true, TILE>(in.r_force, s_tile, p.contact_force_scale, lane);
     } else {  // plain scalar staging
         for (int i = lane; i < nvalid * D; i += WAVE) {
             const int env = i / D, j = i - env * D;
@@ -367,6 +366,13 @@ __device__ __forceinline__ void loco_tile(const igx_loco_params &p, const igx_lo
     // ---- per-env math, part B: the computed columns into the row, reward from the row
     if (live) per_env_b<D, S, HUM, T, IMIT>(p, b, im, e, ea, rnd, s_tile + lane * NOBS, s_lim);
     const f3 up_vec = ea.up_vec, heading_vec = ea.heading_vec;  // lanes without an environment: never stored
+
+    // ---- stage, second half: the pure pass-through columns (sensors, joint forces), requested
+    // last, so that the reward above ran while they were still arriving
+    if constexpr (FULL) {
+        stage_rows<S, L::C_SENS, NOBS, true, TILE>(in.r_sens, s_tile, p.contact_force_scale, lane);
+        if constexpr (HUM) stage_rows<D, L::C_FORCE, NOBS, true, TILE>(in.r_force, s_tile, p.contact_force_scale, lane);
+    }
     wave_sync();
 
     // ---- drain: finished rows out as whole lines
