@@ -538,8 +538,8 @@ static int launch_loco_tile(const igx_loco_params *p, const igx_loco_buffers *b,
 // Launch shape.  Two measured knobs per task (2^20 envs, MI355X): the rows per tile and a
 // reservation of unused LDS that caps the resident waves per CU - this multi-array streaming
 // pattern runs fastest with FEWER waves in flight than the LDS tile alone would allow
-// (Ant: 10 waves/CU 107.4 us, 6 waves 104.5 us, 5 waves 102.7 us, 3 waves 111 us; Humanoid is
-// fastest with 32-row tiles and no reservation).
+// (Ant, 64-row tiles: 10 waves/CU 96.2 us, 7 and 6 waves 94.7 us, 5 waves 96.0 us, 4 waves 99.6 us;
+// Humanoid is fastest with 32-row tiles and no reservation: 168.9 us against 172.8 us with 64-row tiles).
 // IGX_{ANT,HUMANOID}_TILE / _LDS_RESERVE override the defaults for tuning runs.
 template <int D, int S, bool HUM>
 static int launch_loco(const igx_loco_params *p, const igx_loco_buffers *b, int64_t n, igx_stream_t stream,
@@ -547,7 +547,7 @@ static int launch_loco(const igx_loco_params *p, const igx_loco_buffers *b, int6
 {
     if (n == 0) return IGX_OK;
     static const int tile = tuning_int(HUM ? "IGX_HUMANOID_TILE" : "IGX_ANT_TILE", HUM ? 32 : 64);
-    static const int reserve = tuning_int(HUM ? "IGX_HUMANOID_LDS_RESERVE" : "IGX_ANT_LDS_RESERVE", HUM ? 0 : 13000);
+    static const int reserve = tuning_int(HUM ? "IGX_HUMANOID_LDS_RESERVE" : "IGX_ANT_LDS_RESERVE", HUM ? 0 : 8000);
     if (reserve < 0 || reserve > 120 * 1024) return fail(IGX_E_PARAM, "%s: LDS reservation %d out of range", who, reserve);
     if (tile == 32) return launch_loco_tile<D, S, HUM, 32>(p, b, n, reserve, stream, who);
     return launch_loco_tile<D, S, HUM, 64>(p, b, n, reserve, stream, who);
@@ -597,7 +597,7 @@ extern "C" int igx_ant_imitate_observe(const igx_loco_params *p, const igx_loco_
     int rc = igx::check_loco(p, b, n_envs, 8, 24, false, "igx_ant_imitate_observe");
     if (rc == IGX_OK) rc = igx::check_imitate(im, n_envs, "igx_ant_imitate_observe");
     if (rc != IGX_OK || n_envs == 0) return rc;
-    static const int reserve = igx::tuning_int("IGX_ANT_LDS_RESERVE", 13000);
+    static const int reserve = igx::tuning_int("IGX_ANT_LDS_RESERVE", 8000);
     return igx::launch_loco_tile<8, 24, false, 64, true>(p, b, n_envs, reserve, stream, "igx_ant_imitate_observe", im);
 }
 
