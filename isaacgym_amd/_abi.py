@@ -269,3 +269,103 @@ def make_buffers(cls, arrays, ptr_of):
 # igx_allegro_post_physics_static: the library-owned reduction scratch
 IGX_ALLEGRO_STATIC_MAX_ENVS = 1 << 21
 IGX_ALLEGRO_STATIC_SCRATCH_BYTES = 16 * ((1 << 21) // 16 + 1)
+
+
+# ---- how large every buffer of a step call must be ------------------------------------------
+# element counts as include/igx.h documents them: ("env", k) = k elements per environment,
+# ("fixed", k) = k elements whatever the batch, ("bytes", f) = f(n_envs) bytes of opaque scratch,
+# ("rows", k) = rows of k elements addressed through an index tensor (at least one row per environment)
+def IGX_ALLEGRO_WORKSPACE_BYTES(n):
+    return 16 * ((int(n) + 15) // 16 + 1)
+
+
+def IGX_EPISODE_WORKSPACE_BYTES(n):
+    return 32 * ((int(n) + 255) // 256 + 2)
+
+
+def _env(k):
+    return ("env", int(k))
+
+
+_ONE = _env(1)
+
+
+def _cartpole_widths(p):
+    return dict(dof_state=_env(4), rand=_env(4), obs=_env(4), rew=_ONE, reset=_ONE, progress=_ONE)
+
+
+def _loco_widths(p):
+    d, s = int(p.num_dof), int(p.num_sensor_floats)
+    hum = d == 21  # the 21-dof Humanoid also observes its joint forces
+    nobs = 12 + (3 if hum else 2) * d + s + d
+    return dict(root_states=_env(13), dof_state=_env(2 * d), dof_force=_env(d), sensors=_env(s), actions=_env(d),
+                initial_root_states=_env(13), initial_dof_pos=_env(d), rand=_env(2 * d), obs=_env(nobs),
+                potentials=_ONE, prev_potentials=_ONE, up_vec=_env(3), heading_vec=_env(3), rew=_ONE, reset=_ONE,
+                progress=_ONE, randomize=_ONE, true_objective=_ONE, obs_clamped=_env(nobs), time_outs=_ONE)
+
+
+def _hand_widths(dof, actions, rand, nobs, nstates, extra):
+    w = dict(dof_state=_env(2 * dof), dof_force=_env(dof), root_state_tensor=("rows", 13), object_indices=_ONE,
+             goal_object_indices=_ONE, goal_states=_env(13), goal_init_state=_env(13), object_init_state=_env(13),
+             actions=_env(actions), prev_targets=_env(dof), cur_targets=_env(dof), rand=_env(rand), obs=_env(nobs),
+             states=_env(nstates), rew=_ONE, reset=_ONE, reset_goal=_ONE, progress=_ONE, randomize=_ONE,
+             successes=_ONE, consecutive_successes=("fixed", 1), workspace=("bytes", IGX_ALLEGRO_WORKSPACE_BYTES),
+             obs_clamped=_env(nobs), states_clamped=_env(nstates), time_outs=_ONE)
+    w.update(extra)
+    return w
+
+
+def _allegro_widths(p):
+    return _hand_widths(IGX_ALLEGRO_DOF, IGX_ALLEGRO_DOF, IGX_ALLEGRO_RAND_PER_ENV, ALLEGRO_NUM_OBS[int(p.obs_type)], 88, {})
+
+
+_SHADOW_NUM_OBS_BY_TYPE = {0: 42, 1: 77, 2: 157, 3: 211}
+
+
+def _shadow_widths(p):
+    return _hand_widths(IGX_SHADOW_DOF, IGX_SHADOW_ACTIONS, IGX_SHADOW_RAND_PER_ENV,
+                        _SHADOW_NUM_OBS_BY_TYPE[int(p.obs_type)], 211,
+                        dict(vec_sensor_tensor=_env(30), rigid_body_states=_env(13 * max(int(p.num_bodies), 0))))
+
+
+def _amp_widths(p):
+    k = max(int(p.num_amp_obs_steps), 1)
+    return dict(root_states=_env(13), dof_state=_env(2 * IGX_AMP_NUM_DOF), rigid_body_state=_env(13 * IGX_AMP_NUM_BODIES),
+                contact_forces=_env(3 * IGX_AMP_NUM_BODIES), obs=_env(IGX_AMP_OBS), amp_obs=_env(k * IGX_AMP_OBS), rew=_ONE,
+                reset=_ONE, terminate=_ONE, progress=_ONE, obs_clamped=_env(IGX_AMP_OBS), time_outs=_ONE)
+
+
+def _him_widths(p):
+    return dict(root_states=_env(13), dof_state=_env(2 * IGX_HIM_DOF), rigid_body_states=_env(13 * IGX_HIM_BODIES),
+                actions=_env(IGX_HIM_DOF), initial_root_states=_env(13), initial_dof_pos=_env(IGX_HIM_DOF),
+                rand=_env(2 * IGX_HIM_DOF), motion_frame=("fixed", IGX_HIM_DOF + 13 * IGX_HIM_BODIES), obs=_env(IGX_HIM_OBS),
+                potentials=_ONE, prev_potentials=_ONE, rew=_ONE, reset=_ONE, progress=_ONE, randomize=_ONE,
+                obs_clamped=_env(IGX_HIM_OBS), time_outs=_ONE)
+
+
+def _episode_widths(p):
+    return dict(rew=_ONE, done=_ONE, current_rewards=_ONE, current_lengths=_ONE,
+                workspace=("bytes", IGX_EPISODE_WORKSPACE_BYTES))
+
+
+BUFFER_WIDTHS = {CartpoleBuffers: _cartpole_widths, LocoBuffers: _loco_widths, AllegroBuffers: _allegro_widths,
+                 ShadowBuffers: _shadow_widths, AmpBuffers: _amp_widths, HumanoidImitateBuffers: _him_widths,
+                 EpisodeBuffers: _episode_widths}
+
+
+def required_elements(cls, params, n_envs):
+    """field -> (minimum number of elements, or of bytes for opaque scratch, is_bytes) for a call on
+    n_envs environments; None for a struct without a table."""
+    fn = BUFFER_WIDTHS.get(cls)
+    if fn is None:
+        return None
+    out = {}
+    n = int(n_envs)
+    for name, (kind, k) in fn(params).items():
+        if kind == "env" or kind == "rows":
+            out[name] = (k * n, False)
+        elif kind == "fixed":
+            out[name] = (k, False)
+        else:
+            out[name] = (k(n), True)
+    return out

@@ -195,7 +195,67 @@ def make_buffers(cls, tensors):
     return b, dev
 
 
+# IGX_DEBUG_CHECKS=1: also the checks that have to read device memory (and therefore synchronise):
+# index tensors against the number of rows they address
+DEBUG_CHECKS = os.environ.get("IGX_DEBUG_CHECKS", "0") not in ("", "0")
+
+
+def check_sizes(bufcls, params, tensors, n, who):
+    """Every given buffer must hold what a call on n environments reads or writes (a short buffer
+    would be an out-of-bounds device access, not an error code)."""
+    if n < 0:
+        raise ValueError("%s: n_envs %d is negative" % (who, n))
+    need = _abi.required_elements(bufcls, params, n)
+    if need is None:
+        return
+    for k, t in tensors.items():
+        if t is None:
+            continue
+        want = need.get(k)
+        if want is None:
+            continue
+        count, is_bytes = want
+        have = t.numel() * t.element_size() if is_bytes else t.numel()
+        if have < count:
+            raise ValueError("%s: buffer %r holds %d %s, a call on %d environments needs %d" %
+                             (who, k, have, "bytes" if is_bytes else "elements", n, count))
+    if DEBUG_CHECKS and n > 0:
+        rows = tensors.get("root_state_tensor")
+        for k in ("object_indices", "goal_object_indices"):
+            idx = tensors.get(k)
+            if idx is not None and rows is not None and idx.numel():
+                lo, hi = int(idx[:n].min()), int(idx[:n].max())
+                if lo < 0 or hi >= rows.numel() // 13:
+                    raise ValueError("%s: %s addresses rows %d..%d of a %d-row root_state_tensor" %
+                                     (who, k, lo, hi, rows.numel() // 13))
+
+
+def check_env_ids(bufcls, params, tensors, env_ids, who):
+    """reset calls: the buffers are addressed by environment id.  The id list is device memory, so its
+    range is only checked with IGX_DEBUG_CHECKS=1 (it synchronises); the buffers must at least be
+    mutually consistent (all hold the same number of environments)."""
+    widths = _abi.BUFFER_WIDTHS.get(bufcls)
+    if widths is None:
+        return
+    envs = None
+    for k, (kind, w) in widths(params).items():
+        t = tensors.get(k)
+        if t is None or kind != "env" or w == 0:
+            continue
+        have = t.numel() // w
+        envs = have if envs is None else min(envs, have)
+    if envs is None:
+        return
+    if DEBUG_CHECKS and env_ids.numel():
+        hi = int(env_ids.max())
+        if hi >= envs:
+            raise ValueError("%s: env_ids reach %d, the smallest buffer holds %d environments" % (who, hi, envs))
+    if env_ids.numel() > 0 and envs == 0:
+        raise ValueError("%s: env_ids given for buffers that hold no environment" % who)
+
+
 def call_step(symbol, params, bufcls, tensors, n):
+    check_sizes(bufcls, params, tensors, n, symbol)
     b, dev = make_buffers(bufcls, tensors)
     if dev is None:
         raise ValueError("no device buffers given")
@@ -205,6 +265,7 @@ def call_step(symbol, params, bufcls, tensors, n):
 
 
 def call_reset(symbol, params, bufcls, tensors, env_ids):
+    check_env_ids(bufcls, params, tensors, env_ids, symbol)
     b, dev = make_buffers(bufcls, tensors)
     if dev is None:
         raise ValueError("no device buffers given")

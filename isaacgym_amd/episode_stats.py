@@ -37,9 +37,10 @@ class EpisodeStats:
 
     def step(self, rew, done):
         """rew [N] fp32, done [N] int64 (the reset flags `step()` returned); asynchronous."""
-        b, dev = _lib.make_buffers(_abi.EpisodeBuffers, dict(
-            rew=rew, done=done, current_rewards=self.current_rewards, current_lengths=self.current_lengths,
-            workspace=self._ws))
+        t = dict(rew=rew, done=done, current_rewards=self.current_rewards, current_lengths=self.current_lengths,
+                 workspace=self._ws)
+        _lib.check_sizes(_abi.EpisodeBuffers, None, t, self.num_envs, "igx_episode_stats_step")
+        b, dev = _lib.make_buffers(_abi.EpisodeBuffers, t)
         with torch.cuda.device(dev):
             rc = _lib.lib().igx_episode_stats_step(C.byref(b), C.c_int64(self.num_envs), _lib.current_stream(dev))
         _lib.check(rc)

@@ -64,6 +64,8 @@ def allegro_post_physics_shard(params, tensors, n_envs):
 
 def allegro_finalize_shards(params, tensors, records):
     """records: contiguous device tensor of num_shards x 16 bytes, gathered in rank order."""
+    _lib.check_sizes(_abi.AllegroBuffers, params, {"consecutive_successes": tensors.get("consecutive_successes")}, 0,
+                     "igx_allegro_finalize_shards")
     b, dev = _lib.make_buffers(_abi.AllegroBuffers, tensors)
     nbytes = records.numel() * records.element_size()
     if nbytes == 0 or nbytes % 16:
@@ -90,6 +92,8 @@ def shadow_post_physics_shard(params, tensors, n_envs):
 
 def shadow_finalize_shards(params, tensors, records):
     """records: contiguous device tensor of num_shards x 16 bytes, gathered in rank order."""
+    _lib.check_sizes(_abi.ShadowBuffers, params, {"consecutive_successes": tensors.get("consecutive_successes")}, 0,
+                     "igx_shadow_finalize_shards")
     b, dev = _lib.make_buffers(_abi.ShadowBuffers, tensors)
     nbytes = records.numel() * records.element_size()
     if nbytes == 0 or nbytes % 16:
@@ -112,6 +116,15 @@ def motion_tables(tensors):
 
 def motion_state(tables, motion_ids, motion_times, out):
     """out: name -> preallocated device tensor for any subset of igx_motion_state_out."""
+    n = motion_ids.shape[0]
+    if motion_times.shape[0] != n:
+        raise ValueError("igx_motion_state: motion_ids and motion_times differ in length")
+    widths = dict(root_pos=3, root_rot=4, dof_pos=28, root_vel=3, root_ang_vel=3, dof_vel=28, key_pos=12,
+                  frame_idx0=1, frame_idx1=1, blend=1)
+    for k, t in out.items():
+        if t is not None and t.numel() < n * widths.get(k, 0):
+            raise ValueError("igx_motion_state: out[%r] holds %d elements, %d samples need %d" %
+                             (k, t.numel(), n, n * widths[k]))
     o, _ = _lib.make_buffers(_abi.MotionStateOut, out)
     dev = motion_ids.device
     with torch.cuda.device(dev):
@@ -148,6 +161,14 @@ def motion_amp_obs(tables, motion_ids, motion_times, local_root_obs, out, out_ro
                    out_col_offset=0):
     dev = motion_ids.device
     stride = _abi.IGX_AMP_OBS if out_row_stride is None else out_row_stride
+    n = motion_ids.shape[0]
+    if motion_times.shape[0] != n or (out_rows is not None and out_rows.shape[0] != n):
+        raise ValueError("igx_motion_amp_obs: motion_ids, motion_times and out_rows differ in length")
+    if out_col_offset < 0 or out_col_offset + _abi.IGX_AMP_OBS > stride:
+        raise ValueError("igx_motion_amp_obs: a %d-float observation at column %d does not fit a row of %d" %
+                         (_abi.IGX_AMP_OBS, out_col_offset, stride))
+    if out_rows is None and out.numel() < n * stride:
+        raise ValueError("igx_motion_amp_obs: out holds %d floats, %d samples need %d" % (out.numel(), n, n * stride))
     with torch.cuda.device(dev):
         rc = _lib.lib().igx_motion_amp_obs(C.byref(tables), _lib.tensor_ptr(motion_ids, torch.int64),
                                            _lib.tensor_ptr(motion_times, torch.float64),
@@ -161,6 +182,11 @@ def motion_amp_obs(tables, motion_ids, motion_times, local_root_obs, out, out_ro
 def amp_observations(root_states, dof_pos, dof_vel, key_body_pos, local_root_obs, obs):
     dev = obs.device
     f = torch.float32
+    n = obs.shape[0]
+    for name, t, w in (("root_states", root_states, 13), ("dof_pos", dof_pos, 28), ("dof_vel", dof_vel, 28),
+                       ("key_body_pos", key_body_pos, 12), ("obs", obs, _abi.IGX_AMP_OBS)):
+        if t.numel() < n * w:
+            raise ValueError("igx_amp_observations: %s holds %d floats, %d rows need %d" % (name, t.numel(), n, n * w))
     with torch.cuda.device(dev):
         rc = _lib.lib().igx_amp_observations(_lib.tensor_ptr(root_states, f), _lib.tensor_ptr(dof_pos, f),
                                              _lib.tensor_ptr(dof_vel, f), _lib.tensor_ptr(key_body_pos, f),
@@ -175,6 +201,12 @@ def humanoid_amp_step(params, tensors, n_envs):
 
 def humanoid_amp_reset(params, tensors, env_ids, state):
     """state: root_pos / root_rot / dof_pos / root_vel / root_ang_vel / dof_vel rows for env_ids."""
+    _lib.check_env_ids(_abi.AmpBuffers, params, tensors, env_ids, "igx_humanoid_amp_reset")
+    m = env_ids.shape[0]
+    for k, w in (("root_pos", 3), ("root_rot", 4), ("dof_pos", 28), ("root_vel", 3), ("root_ang_vel", 3), ("dof_vel", 28)):
+        t = state.get(k)  # a missing entry leaves that part of the environment's state as it is
+        if t is not None and t.numel() < m * w:
+            raise ValueError("igx_humanoid_amp_reset: state[%r] must hold %d x %d floats" % (k, m, w))
     b, dev = _lib.make_buffers(_abi.AmpBuffers, tensors)
     st, _ = _lib.make_buffers(_abi.MotionStateOut, state)
     with torch.cuda.device(dev):
@@ -328,6 +360,7 @@ def imitate_args(motion, target_pose_idx, pose_diff, workspace, quantile, distan
 
 
 def _imitate_call(symbol, params, tensors, im, n_envs):
+    _lib.check_sizes(_abi.LocoBuffers, params, tensors, n_envs, symbol)
     b, dev = _lib.make_buffers(_abi.LocoBuffers, tensors)
     with torch.cuda.device(dev):
         rc = getattr(_lib.lib(), symbol)(C.byref(params), C.byref(b), C.byref(im), C.c_int64(n_envs),
