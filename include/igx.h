@@ -458,6 +458,41 @@ int igx_shadow_finalize_shards(const igx_shadow_params *p, const igx_shadow_buff
                                int32_t num_shards, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Random disturbance forces on the manipulated object of AllegroHand / ShadowHand: everything
+ * pre_physics_step does to rb_forces and random_force_prob around
+ * apply_rigid_body_force_tensors (tasks/allegro_hand.py:532, :558-559, :617-625;
+ * tasks/shadow_hand.py:616, :642-643, :700-708).  Per environment, in the reference's order:
+ *   reset[e] != 0:  rb_forces[e, :, :] = 0;
+ *                   random_force_prob[e] = exp((log_prob_lo - log_prob_hi) * u_prob + log_prob_hi)
+ *   rb_forces[e, :, :] *= decay
+ *   u_sel < random_force_prob[e]:  rb_forces[e, object_rb_handle, :] = (z * object_rb_mass) * force_scale
+ * Call it BEFORE igx_allegro_pre_physics / igx_shadow_pre_physics of the same step, which clear the
+ * reset flags it reads (nothing else is shared between the two calls).  The object is one rigid body,
+ * as in the reference's assets.  rand, when given, holds per environment
+ * (u_prob, u_sel, z0, z1, z2): two uniforms in [0,1) and three standard normals - torch's own
+ * draws scattered to their environments reproduce the reference bit for bit (random_force_prob to
+ * the last bit of exp); NULL = the library's Philox4x32-10 stream with Box-Muller normals.
+ * ---------------------------------------------------------------------- */
+#define IGX_HAND_FORCE_RAND_PER_ENV 5
+typedef struct igx_hand_forces {
+    float *rb_forces;            /* [N, num_bodies, 3] in/out */
+    float *random_force_prob;    /* [N] in/out */
+    const int64_t *reset;        /* [N] reset_buf as pre_physics_step finds it */
+    const float *rand;           /* [N,5] or NULL */
+    int32_t num_bodies;          /* rigid bodies per environment */
+    int32_t object_rb_handle;    /* the object's body index in [0, num_bodies) */
+    float object_rb_mass;
+    float force_scale;           /* env.forceScale */
+    float decay;                 /* float32 pow(env.forceDecay, dt / env.forceDecayInterval) */
+    float log_prob_lo, log_prob_hi; /* float32 log of env.forceProbRange[0], [1] */
+    int32_t reserved;
+    uint64_t seed, rng_offset;
+    const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+} igx_hand_forces;
+
+int igx_hand_random_forces(const igx_hand_forces *f, int64_t n_envs, igx_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * HumanoidAMP and the AMP motion library.  The character is the reference's
  * 15-body / 28-dof AMP humanoid: DOF_BODY_IDS, DOF_OFFSETS and the four key
  * bodies are fixed as in tasks/amp/humanoid_amp_base.py:43-49.

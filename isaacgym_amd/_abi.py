@@ -148,6 +148,16 @@ class ShadowBuffers(_Struct):
                 ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr)]
 
 
+IGX_HAND_FORCE_RAND_PER_ENV = 5
+
+
+class HandForces(_Struct):
+    _fields_ = [("rb_forces", ptr), ("random_force_prob", ptr), ("reset", ptr), ("rand", ptr),
+                ("num_bodies", i32), ("object_rb_handle", i32), ("object_rb_mass", f32), ("force_scale", f32),
+                ("decay", f32), ("log_prob_lo", f32), ("log_prob_hi", f32), ("reserved", i32),
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+
+
 IGX_AMP_NUM_BODIES = 15
 IGX_AMP_NUM_DOF = 28
 IGX_AMP_NUM_KEY_BODIES = 4

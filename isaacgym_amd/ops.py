@@ -76,6 +76,42 @@ def allegro_finalize_shards(params, tensors, records):
     _lib.check(rc)
 
 
+def hand_force_constants(force_decay, dt, force_decay_interval, force_prob_range):
+    """(decay, log_prob_lo, log_prob_hi) as the reference's float32 torch expressions give them
+    (tasks/allegro_hand.py:191-194, :558, :618): evaluated once on the host with the same torch CPU ops."""
+    decay = float(torch.pow(torch.tensor(float(force_decay), dtype=torch.float32), dt / force_decay_interval))
+    rng = torch.tensor([float(force_prob_range[0]), float(force_prob_range[1])], dtype=torch.float32)
+    logs = torch.log(rng)
+    return decay, float(logs[0]), float(logs[1])
+
+
+def hand_random_forces(rb_forces, random_force_prob, reset, object_rb_handle, object_rb_mass, force_scale, decay,
+                       log_prob_lo, log_prob_hi, rand=None, seed=0, rng_offset=0, rng_offset_dev=None):
+    """igx_hand_random_forces on rb_forces [N, B, 3]: zero + re-draw for flagged environments, decay, new object
+    forces where the Bernoulli draw says so.  Call before the task's pre-physics kernel of the same step."""
+    if rb_forces.dim() != 3 or rb_forces.shape[2] != 3:
+        raise ValueError("rb_forces must be [num_envs, num_bodies, 3]")
+    n, nb = rb_forces.shape[0], rb_forces.shape[1]
+    if random_force_prob.numel() < n or reset.numel() < n:
+        raise ValueError("random_force_prob and reset must have one entry per environment")
+    if rand is not None and rand.numel() < n * _abi.IGX_HAND_FORCE_RAND_PER_ENV:
+        raise ValueError("rand must be [num_envs, %d]" % _abi.IGX_HAND_FORCE_RAND_PER_ENV)
+    dev = rb_forces.device
+    f = torch.float32
+    s = _abi.HandForces(rb_forces=_lib.tensor_ptr(rb_forces, f), random_force_prob=_lib.tensor_ptr(random_force_prob, f),
+                        reset=_lib.tensor_ptr(reset, torch.int64), rand=_lib.tensor_ptr(rand, f) if rand is not None else None,
+                        num_bodies=int(nb), object_rb_handle=int(object_rb_handle), object_rb_mass=float(object_rb_mass),
+                        force_scale=float(force_scale), decay=float(decay), log_prob_lo=float(log_prob_lo),
+                        log_prob_hi=float(log_prob_hi), seed=int(seed), rng_offset=int(rng_offset),
+                        rng_offset_dev=rng_offset_dev)
+    for t in (random_force_prob, reset) + ((rand,) if rand is not None else ()):
+        if t.device != dev:
+            raise ValueError("all tensors must live on %s" % dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_hand_random_forces(C.byref(s), C.c_int64(n), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 # ---- ShadowHand ------------------------------------------------------------------------------
 def shadow_pre_physics(params, tensors, n_envs):
     _lib.call_step("igx_shadow_pre_physics", params, _abi.ShadowBuffers, tensors, n_envs)

@@ -50,6 +50,10 @@ class TensorSim:
     def apply_dof_position_targets(self, targets):
         self.tensors["dof_position_target"] = targets
 
+    def apply_rigid_body_forces(self, forces):
+        """gym.apply_rigid_body_force_tensors(sim, forces, None, LOCAL_SPACE)"""
+        self.tensors["rigid_body_force"] = forces
+
 
 _PHYSICS_OWNED = {
     "Cartpole": ("dof_state",),
@@ -110,11 +114,12 @@ class SyntheticSim(TensorSim):
             p = synthetic.shadow_params()
             self.asset = dict(dof_limits_lower=list(p.dof_lower), dof_limits_upper=list(p.dof_upper),
                               num_dof=_abi.IGX_SHADOW_DOF, actuated_dof_indices=list(synthetic.SHADOW_ACTUATED),
-                              fingertip_handles=list(synthetic.SHADOW_FINGERTIPS))
+                              fingertip_handles=list(synthetic.SHADOW_FINGERTIPS),
+                              num_bodies=int(p.num_bodies), object_rb_handle=int(p.num_bodies) - 2, object_rb_mass=0.1)
         elif task == "AllegroHand":
             p = synthetic.allegro_params()
             self.asset = dict(dof_limits_lower=list(p.dof_lower), dof_limits_upper=list(p.dof_upper),
-                              num_dof=_abi.IGX_ALLEGRO_DOF)
+                              num_dof=_abi.IGX_ALLEGRO_DOF, num_bodies=23, object_rb_handle=21, object_rb_mass=0.1)
 
     def simulate(self):
         super().simulate()

@@ -19,9 +19,10 @@ import torch
 from .. import _abi, distributed, ops, synthetic
 from .allegro_hand import success_threshold_c
 from .base.vec_task import VecTask
+from .hand_forces import HandForcesMixin
 
 
-class ShadowHand(VecTask):
+class ShadowHand(HandForcesMixin, VecTask):
     def __init__(self, cfg, rl_device, sim_device, graphics_device_id=0, headless=True, virtual_screen_capture=False,
                  force_render=False, sim=None, seed=0, process_group=None):
         self.cfg = cfg
@@ -44,8 +45,6 @@ class ShadowHand(VecTask):
         self.reset_dof_pos_noise = env["resetDofPosRandomInterval"]
         self.reset_dof_vel_noise = env["resetDofVelRandomInterval"]
         self.force_scale = env.get("forceScale", 0.0)
-        if self.force_scale > 0.0:
-            raise NotImplementedError("random object forces (forceScale > 0) are applied inside the physics engine")
         self.shadow_hand_dof_speed_scale = env["dofSpeedScale"]
         self.use_relative_control = env["useRelativeControl"]
         self.act_moving_average = env["actionsMovingAverage"]
@@ -115,6 +114,7 @@ class ShadowHand(VecTask):
         self._success_c = success_threshold_c(tol)
         av32 = float(torch.tensor(self.av_factor, dtype=torch.float32))
         self._one_minus_av = 1.0 - av32
+        self._init_forces(env)  # rb_forces, random_force_prob (forceScale > 0: random object forces)
 
     _PARAM_KEY = ("obs_type", "max_consecutive_successes", "ignore_z", "use_relative_control", "dist_reward_scale",
                   "rot_reward_scale", "rot_eps", "action_penalty_scale", "success_tolerance", "reach_goal_bonus", "fall_dist",
@@ -169,6 +169,7 @@ class ShadowHand(VecTask):
         if self.randomize and bool(self.reset_buf.any()):
             self.apply_randomizations(self.randomization_params)
         self.actions = actions.to(self.device).clone()
+        self._apply_random_forces()  # :616, :642-643, :700-708; reads reset_buf before the kernel below clears it
         ops.shadow_pre_physics(self._params(), self._buffers(), self.num_envs)
         self.sim.notify_root_state(self.root_state_tensor)
         self.sim.notify_dof_state()

@@ -66,6 +66,35 @@ def _install_gym_stubs():
     gt = sys.modules["isaacgym.gymtorch"]
     gt.unwrap_tensor = lambda t: t
     gt.wrap_tensor = lambda t: t
+    sys.modules["isaacgym.gymapi"].LOCAL_SPACE = 0  # an enum of the engine, only ever passed back to it
+
+
+def _replay_draws(state, specs):
+    """Re-draw what torch.rand / torch.randn produced after RNG state `state`; specs are
+    ("rand" | "randn", shape) in call order, or a callable(previous draws) -> such a pair."""
+    keep = torch.get_rng_state()
+    torch.set_rng_state(state)
+    out = []
+    for spec in specs:
+        kind, shape = spec(out) if callable(spec) else spec
+        out.append(torch.rand(*shape) if kind == "rand" else torch.randn(*shape))
+    torch.set_rng_state(keep)
+    return out
+
+
+def _force_draws(t, N, st, shapes, env_ids):
+    """The draws of the random-force block of pre_physics_step (tasks/allegro_hand.py:558-559, :617-625),
+    scattered to their environments: [N,5] = (u of the probability re-draw, Bernoulli u, three normals)."""
+    specs = [("rand", s) for s in shapes] + [("rand", (N,)),
+             lambda prev: ("randn", (int((prev[-1] < t.random_force_prob).sum()), 1, 3))]
+    draws = _replay_draws(st, specs)
+    dense = np.zeros((N, 5), np.float32)
+    if len(env_ids) > 0:
+        dense[env_ids.numpy(), 0] = draws[len(shapes) - 1].numpy()  # the (len(env_ids),) draw closes reset_idx's list
+    dense[:, 1] = draws[-2].numpy()
+    sel = (draws[-2] < t.random_force_prob).nonzero().squeeze(-1).numpy()
+    dense[sel, 2:5] = draws[-1].numpy().reshape(-1, 3)
+    return dense, len(sel)
 
 
 def _replay_uniforms(state, shapes):
@@ -795,7 +824,8 @@ def success_threshold_c(tol):
 
 
 def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, object_type="block",
-                 max_consecutive_successes=0, use_relative_control=False, act_moving_average=None):
+                 max_consecutive_successes=0, use_relative_control=False, act_moving_average=None,
+                 force_scale=None, force_prob_range=(0.001, 0.1)):
     _install_gym_stubs()
     mod = ref_shim.load("isaacgymenvs.tasks.allegro_hand")
     tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
@@ -827,7 +857,7 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
     t.reset_rotation_noise = e["resetRotationNoise"]
     t.reset_dof_pos_noise = e["resetDofPosRandomInterval"]
     t.reset_dof_vel_noise = e["resetDofVelRandomInterval"]
-    t.force_scale = e.get("forceScale", 0.0)
+    t.force_scale = e.get("forceScale", 0.0) if force_scale is None else force_scale
     t.shadow_hand_dof_speed_scale = e["dofSpeedScale"]
     t.use_relative_control = use_relative_control
     t.act_moving_average = e["actionsMovingAverage"] if act_moving_average is None else act_moving_average
@@ -882,7 +912,8 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
     t.successes = torch.zeros(N)
     t.consecutive_successes = torch.zeros(1)
     t.force_decay = torch.tensor(0.99)
-    t.force_prob_range = torch.tensor([0.001, 0.1])
+    t.force_prob_range = torch.tensor([float(force_prob_range[0]), float(force_prob_range[1])])
+    t.force_decay_interval = e.get("forceDecayInterval", 0.08)
     t.random_force_prob = torch.zeros(N)
     t.rb_forces = torch.zeros(N, 4, 3)
     t.object_rb_handles = torch.tensor([2])
@@ -894,6 +925,8 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
             "pre_reset", "pre_reset_goal", "pre_progress", "pre_successes",
             "in_dof_state", "in_dof_force", "in_root", "obs", "states", "rew", "reset", "reset_goal", "progress",
             "successes", "consecutive_successes", "randomize"]
+    if t.force_scale > 0.0:
+        keys += ["force_rand", "pre_rb_forces", "pre_random_force_prob"]
     rec = {k: [] for k in keys}
     init = {"dof_lower": lo.numpy().copy(), "dof_upper": hi.numpy().copy(),
             "object_init_state": t.object_init_state.numpy().copy(),
@@ -902,6 +935,7 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
             "object_indices": t.object_indices.numpy().copy(),
             "goal_object_indices": t.goal_object_indices.numpy().copy()}
     torch.manual_seed(seed + 100)
+    selected_total = 0
     for step in range(T):
         # a few envs near the end of the episode, a few with only the goal flag
         if step == 1:
@@ -927,6 +961,12 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
             dense[env_ids.numpy(), 4:41] = draws[k].numpy()
             dense[env_ids.numpy(), 41:45] = draws[k + 1].numpy()
         rec["rand"].append(dense)
+        if t.force_scale > 0.0:
+            fr, nsel = _force_draws(t, N, st, shapes, env_ids)
+            rec["force_rand"].append(fr)
+            rec["pre_rb_forces"].append(t.rb_forces.numpy().copy())
+            rec["pre_random_force_prob"].append(t.random_force_prob.numpy().copy())
+            selected_total += nsel
         rec["pre_dof_state"].append(t.dof_state.numpy().copy())
         rec["pre_root"].append(t.root_state_tensor.numpy().copy())
         rec["pre_goal_states"].append(t.goal_states.numpy().copy())
@@ -987,7 +1027,12 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
                         av_factor=av, one_minus_av_factor=1.0 - av,
                         reset_position_noise=t.reset_position_noise, reset_dof_pos_noise=t.reset_dof_pos_noise,
                         reset_dof_vel_noise=t.reset_dof_vel_noise, act_moving_average=float(t.act_moving_average),
-                        dof_speed_scale_dt=t.shadow_hand_dof_speed_scale * t.dt)
+                        dof_speed_scale_dt=t.shadow_hand_dof_speed_scale * t.dt,
+                        force_scale=float(t.force_scale), force_decay=float(t.force_decay), dt=float(t.dt),
+                        force_decay_interval=float(t.force_decay_interval),
+                        force_prob_range=[float(x) for x in force_prob_range],
+                        object_rb_handle=int(t.object_rb_handles[0]), object_rb_mass=float(t.object_rb_masses[0]),
+                        num_rb_force_bodies=int(t.rb_forces.shape[1]), forces_selected=selected_total)
     np.savez_compressed(os.path.join(OUT, "allegro_%s.npz" % name), **out)
     print("allegro_%s.npz" % name, "N", N, "T", T, "c*", cstar,
           "successes", int(out["reset_goal"].sum()), "resets", int(out["reset"].sum()))
@@ -1002,8 +1047,16 @@ def gen_allegro():
     _gen_allegro("ema", N=96, T=2, seed=9, act_moving_average=0.3)
 
 
+def gen_hand_forces():
+    """forceScale > 0: the random disturbance forces of both hand tasks (rb_forces decay, Bernoulli
+    selection against random_force_prob, randn * mass * force_scale, log-uniform re-draw on reset)."""
+    _gen_allegro("force", N=160, T=4, seed=10, force_scale=1.0, force_prob_range=(0.05, 0.6))
+    _gen_shadow("force", N=70, T=3, seed=18, force_scale=0.5, force_prob_range=(0.02, 0.5))
+
+
 def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, object_type="block",
-                max_consecutive_successes=0, use_relative_control=False, act_moving_average=None):
+                max_consecutive_successes=0, use_relative_control=False, act_moving_average=None,
+                force_scale=None, force_prob_range=(0.001, 0.1)):
     """ShadowHand (tasks/shadow_hand.py): pre_physics_step (resets + targets of the 20 actuated joints)
     and post_physics_step (observation layouts :473-584, compute_hand_reward :747-800) of the reference
     class on synthetic simulator tensors."""
@@ -1036,7 +1089,7 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
         setattr(t, k_attr, e[k_cfg])
     t.vel_obs_scale = 0.2
     t.force_torque_obs_scale = 10.0
-    t.force_scale = e.get("forceScale", 0.0)
+    t.force_scale = e.get("forceScale", 0.0) if force_scale is None else force_scale
     t.use_relative_control = use_relative_control
     t.act_moving_average = e["actionsMovingAverage"] if act_moving_average is None else act_moving_average
     t.print_success_stat = False
@@ -1095,7 +1148,8 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
     t.successes = torch.zeros(N)
     t.consecutive_successes = torch.zeros(1)
     t.force_decay = torch.tensor(0.99)
-    t.force_prob_range = torch.tensor([0.001, 0.1])
+    t.force_prob_range = torch.tensor([float(force_prob_range[0]), float(force_prob_range[1])])
+    t.force_decay_interval = e.get("forceDecayInterval", 0.08)
     t.random_force_prob = torch.zeros(N)
     t.rb_forces = torch.zeros(N, NB, 3)
     t.object_rb_handles = torch.tensor([26])
@@ -1107,6 +1161,8 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
             "pre_reset", "pre_reset_goal", "pre_progress", "pre_successes",
             "in_dof_state", "in_dof_force", "in_sensors", "in_bodies", "in_root", "obs", "states", "rew", "reset",
             "reset_goal", "progress", "successes", "consecutive_successes", "randomize"]
+    if t.force_scale > 0.0:
+        keys += ["force_rand", "pre_rb_forces", "pre_random_force_prob"]
     rec = {k: [] for k in keys}
     init = {"dof_lower": lo.numpy().copy(), "dof_upper": hi.numpy().copy(),
             "object_init_state": t.object_init_state.numpy().copy(),
@@ -1118,6 +1174,7 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
             "fingertip_handles": t.fingertip_handles.numpy().astype(np.int32)}
     R = 61
     torch.manual_seed(seed + 100)
+    selected_total = 0
     for step in range(T):
         if step == 1:  # a few envs near the end of the episode
             L = t.max_episode_length
@@ -1143,6 +1200,12 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
             dense[env_ids.numpy(), 4:4 + 2 * D + 5] = draws[k].numpy()
             dense[env_ids.numpy(), 4 + 2 * D + 5:R] = draws[k + 1].numpy()
         rec["rand"].append(dense)
+        if t.force_scale > 0.0:
+            fr, nsel = _force_draws(t, N, st, shapes, env_ids)
+            rec["force_rand"].append(fr)
+            rec["pre_rb_forces"].append(t.rb_forces.numpy().copy())
+            rec["pre_random_force_prob"].append(t.random_force_prob.numpy().copy())
+            selected_total += nsel
         rec["pre_dof_state"].append(t.dof_state.numpy().copy())
         rec["pre_root"].append(t.root_state_tensor.numpy().copy())
         rec["pre_goal_states"].append(t.goal_states.numpy().copy())
@@ -1207,7 +1270,12 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
                         av_factor=av, one_minus_av_factor=1.0 - av,
                         reset_position_noise=t.reset_position_noise, reset_dof_pos_noise=t.reset_dof_pos_noise,
                         reset_dof_vel_noise=t.reset_dof_vel_noise, act_moving_average=float(t.act_moving_average),
-                        dof_speed_scale_dt=t.shadow_hand_dof_speed_scale * t.dt)
+                        dof_speed_scale_dt=t.shadow_hand_dof_speed_scale * t.dt,
+                        force_scale=float(t.force_scale), force_decay=float(t.force_decay), dt=float(t.dt),
+                        force_decay_interval=float(t.force_decay_interval),
+                        force_prob_range=[float(x) for x in force_prob_range],
+                        object_rb_handle=int(t.object_rb_handles[0]), object_rb_mass=float(t.object_rb_masses[0]),
+                        num_rb_force_bodies=int(t.rb_forces.shape[1]), forces_selected=selected_total)
     np.savez_compressed(os.path.join(OUT, "shadow_%s.npz" % name), **out)
     print("shadow_%s.npz" % name, "N", N, "T", T, "c*", cstar,
           "successes", int(out["reset_goal"].sum()), "resets", int(out["reset"].sum()))
@@ -1753,7 +1821,7 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+GENERATORS = {"hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

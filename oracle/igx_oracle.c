@@ -1844,3 +1844,38 @@ int orc_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_hu
     }
     return 0;
 }
+
+/* ------------------------------------------------- hand disturbance forces --- */
+/* tasks/allegro_hand.py:532 (rb_forces[env_ids] = 0 in reset_idx), :558-559 (log-uniform re-draw of
+ * random_force_prob on reset), :617-625 (decay, Bernoulli selection, randn * mass * force_scale into
+ * the object's body rows); tasks/shadow_hand.py:616, :642-643, :700-708 are the same lines. */
+int orc_hand_random_forces(const igx_hand_forces *f, int64_t n)
+{
+    if (!f || n < 0) return -1;
+    const int nb = f->num_bodies;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        float u_prob, u_sel, z[3];
+        if (f->rand) {
+            const float *r = f->rand + e * IGX_HAND_FORCE_RAND_PER_ENV;
+            u_prob = r[0]; u_sel = r[1]; z[0] = r[2]; z[1] = r[3]; z[2] = r[4];
+        } else {  /* the library's own stream: uniforms 0..5 of the environment, Box-Muller on (2,3) and (4,5) */
+            const float u2 = orc_philox_uniform(f->seed, f->rng_offset, e, 2), u3 = orc_philox_uniform(f->seed, f->rng_offset, e, 3);
+            const float v0 = orc_philox_uniform(f->seed, f->rng_offset, e, 4), v1 = orc_philox_uniform(f->seed, f->rng_offset, e, 5);
+            u_prob = orc_philox_uniform(f->seed, f->rng_offset, e, 0);
+            u_sel = orc_philox_uniform(f->seed, f->rng_offset, e, 1);
+            const float r0 = sqrtf(-2.0f * logf(1.0f - u2)), a0 = 6.2831855f * u3;
+            const float r1 = sqrtf(-2.0f * logf(1.0f - v0)), a1 = 6.2831855f * v1;
+            z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1);
+        }
+        float *rows = f->rb_forces + e * nb * 3;
+        if (f->reset[e] != 0) {
+            for (int i = 0; i < nb * 3; ++i) rows[i] = 0.0f;
+            f->random_force_prob[e] = expf((f->log_prob_lo - f->log_prob_hi) * u_prob + f->log_prob_hi);
+        }
+        for (int i = 0; i < nb * 3; ++i) rows[i] = rows[i] * f->decay;
+        if (u_sel < f->random_force_prob[e])
+            for (int c = 0; c < 3; ++c) rows[f->object_rb_handle * 3 + c] = (z[c] * f->object_rb_mass) * f->force_scale;
+    }
+    return 0;
+}

@@ -94,7 +94,7 @@ def loco_params(meta, g, seed=0, rng_offset=0):
 LOCO_ANGLE_COLS = (7, 8, 9)
 
 
-ALLEGRO_VARIANTS = ["default", "full", "no_vel_asym", "pen_maxsucc", "relative", "ema"]
+ALLEGRO_VARIANTS = ["default", "full", "no_vel_asym", "pen_maxsucc", "relative", "ema", "force"]
 
 
 def allegro_params(meta, g, seed=0, rng_offset=0):
@@ -118,7 +118,52 @@ def allegro_params(meta, g, seed=0, rng_offset=0):
         dof_lower=g["dof_lower"], dof_upper=g["dof_upper"], seed=seed, rng_offset=rng_offset)
 
 
-def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
+class ForceReplay:
+    """The random-force block of a hand task's pre_physics_step (forceScale > 0 recordings): runs
+    force_fn ahead of the pre-physics call of every step, on the reference's own draws, and checks
+    rb_forces / random_force_prob against what the reference class left behind."""
+
+    def __init__(self, g, force_fn, to_buf, to_np, zeros):
+        from isaacgym_amd import ops
+        m = g["meta"]
+        self.g, self.fn, self.to_buf, self.to_np = g, force_fn, to_buf, to_np
+        self.on = force_fn is not None and "force_rand" in g
+        if "force_rand" in g and force_fn is None:
+            raise AssertionError("this recording has forceScale > 0: pass force_fn")
+        if not self.on:
+            return
+        N, NB = m["N"], m["num_rb_force_bodies"]
+        self.rb = zeros((N, NB, 3), np.float32)
+        self.prob = zeros((N,), np.float32)
+        self.rand = zeros((N, 5), np.float32)
+        decay, lo, hi = ops.hand_force_constants(m["force_decay"], m["dt"], m["force_decay_interval"], m["force_prob_range"])
+        self.kw = dict(object_rb_handle=m["object_rb_handle"], object_rb_mass=m["object_rb_mass"],
+                       force_scale=m["force_scale"], decay=decay, log_prob_lo=lo, log_prob_hi=hi)
+
+    def _put(self, dst, arr):
+        src = self.to_buf(np.ascontiguousarray(arr).reshape(tuple(dst.shape)))
+        if hasattr(dst, "copy_"):
+            dst.copy_(src)
+        else:
+            dst[...] = src
+
+    def before_pre(self, t, reset):
+        if self.on:
+            self._put(self.rand, self.g["force_rand"][t])
+            self.fn(self.rb, self.prob, reset, rand=self.rand, **self.kw)
+
+    def after_pre(self, t):
+        if not self.on:
+            return
+        what = "pre step %d " % t
+        # the probability goes through exp (1e-6 class); the forces are products of the given draws: bit for bit
+        assert_close(self.to_np(self.prob), self.g["pre_random_force_prob"][t], rtol=2e-6, what=what + "random_force_prob")
+        assert bit_equal_fraction(self.to_np(self.rb), self.g["pre_rb_forces"][t]) == 1.0, what + "rb_forces"
+        assert (self.g["pre_rb_forces"][t] != 0).any()
+        self._put(self.prob, self.g["pre_random_force_prob"][t])  # continue from the reference's own values
+
+
+def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros, force_fn=None):
     """Replay an AllegroHand golden file through pre_fn / post_fn.
 
     to_buf(array) -> backend buffer, to_np(buffer) -> numpy, zeros(shape, dtype)
@@ -147,6 +192,7 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         else:
             dst[...] = src
 
+    forces = ForceReplay(g, force_fn, to_buf, to_np, zeros)
     rot_cols = [3, 4, 5, 6]
     for t in range(T):
         if t == 1:
@@ -155,7 +201,9 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
             put("progress", prog)
         put("actions", g["actions"][t])
         put("rand", g["rand"][t])
+        forces.before_pre(t, b["reset"])
         pre_fn(p, b, N)
+        forces.after_pre(t)
         what = "pre step %d " % t
         for k, ref in (("reset", g["pre_reset"][t]), ("reset_goal", g["pre_reset_goal"][t]),
                        ("progress", g["pre_progress"][t])):
@@ -189,7 +237,7 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
 
-SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen"]
+SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen", "force"]
 
 
 def shadow_params(meta, g, seed=0, rng_offset=0):
@@ -215,7 +263,7 @@ def shadow_params(meta, g, seed=0, rng_offset=0):
         fingertip_handles=[int(x) for x in g["fingertip_handles"]], seed=seed, rng_offset=rng_offset)
 
 
-def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
+def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros, force_fn=None):
     """Replay a ShadowHand golden file through pre_fn / post_fn (see allegro_replay)."""
     m = g["meta"]
     N, T, NB = m["N"], m["T"], m["num_bodies"]
@@ -242,6 +290,7 @@ def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
         else:
             dst[...] = src
 
+    forces = ForceReplay(g, force_fn, to_buf, to_np, zeros)
     rot_cols = [3, 4, 5, 6]
     L = m["max_episode_length"]
     for t in range(T):
@@ -251,7 +300,9 @@ def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros):
             put("progress", prog)
         put("actions", g["actions"][t])
         put("rand", g["rand"][t])
+        forces.before_pre(t, b["reset"])
         pre_fn(p, b, N)
+        forces.after_pre(t)
         what = "pre step %d " % t
         for k, ref in (("reset", g["pre_reset"][t]), ("reset_goal", g["pre_reset_goal"][t]),
                        ("progress", g["pre_progress"][t])):

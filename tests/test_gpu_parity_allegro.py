@@ -20,7 +20,8 @@ def test_allegro_golden(variant):
                      to_buf=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV),
                      to_np=lambda t: t.cpu().numpy(),
                      zeros=lambda shape, dt: torch.zeros(shape, device=DEV,
-                                                         dtype=torch.int64 if dt == np.int64 else torch.float32))
+                                                         dtype=torch.int64 if dt == np.int64 else torch.float32),
+                     force_fn=ops.hand_random_forces)
 
 
 @pytest.mark.parametrize("n,obs_type,asym", [(0, "full_state", False), (1, "full_state", False),

@@ -476,3 +476,53 @@ def test_amp_demo_batches_stream_to_the_host(motion_lib):
     for c in (0, 1, 104, 105, width - 1):
         assert torch.equal(got["c%d" % c], torch.stack([w[:, c] for w in want], 1).cpu()), c
     assert len({float(w.sum()) for w in want}) == steps    # every batch was a new sample
+
+
+# ------------------------------------------------------------------------- random object forces
+@pytest.mark.parametrize("name,nact", [("AllegroHand", 16), ("ShadowHand", 20)])
+def test_hand_random_forces_through_the_class(name, nact):
+    """forceScale > 0: the task keeps rb_forces / random_force_prob as the reference does
+    (allegro_hand.py:532, :558-559, :617-625); given the draws, the class path equals the CPU checker."""
+    n = 3000
+    task = tasks.make(name, n, DEV, seed=4, forceScale=0.7, forceProbRange=[0.05, 0.5])
+    assert task.rb_forces.shape == (n, task.num_bodies, 3) and task.random_force_prob.shape == (n,)
+    lo, hi = 0.05, 0.5
+    assert float(task.random_force_prob.min()) >= lo * 0.999 and float(task.random_force_prob.max()) <= hi * 1.001
+    g = torch.Generator().manual_seed(3)
+    from isaacgym_amd import ops as _ops
+    consts = _ops.hand_force_constants(0.99, task.dt, 0.08, [lo, hi])
+    for step in range(3):
+        draws = torch.cat([torch.rand(n, 2, generator=g), torch.randn(n, 3, generator=g)], dim=1).contiguous()
+        task.force_rand = draws.to(DEV)
+        rb = task.rb_forces.cpu().numpy().copy()
+        prob = task.random_force_prob.cpu().numpy().copy()
+        rst = task.reset_buf.cpu().numpy().copy()
+        oracle.hand_random_forces(rb, prob, rst, task.object_rb_handles[0], task.object_rb_masses[0], 0.7, consts[0],
+                                  consts[1], consts[2], rand=draws.numpy())
+        task.step(torch.rand(n, nact, device=DEV) * 2 - 1)
+        assert np.array_equal(task.rb_forces.cpu().numpy().view(np.uint32), rb.view(np.uint32)), "rb_forces step %d" % step
+        H.assert_close(task.random_force_prob.cpu().numpy(), prob, rtol=2e-6, what="random_force_prob")
+        assert task.sim.tensors["rigid_body_force"] is task.rb_forces
+        if step == 0:
+            assert rst.all()  # reset_buf starts at ones: every environment re-drew its probability
+    assert (task.rb_forces != 0).any()
+    other = [b for b in range(task.num_bodies) if b != task.object_rb_handles[0]]
+    assert not (task.rb_forces[:, other] != 0).any()
+    # in-kernel draws: same distributions (selection rate = mean probability, forces ~ N(0, (mass * scale)^2))
+    task.force_rand = None
+    sel = 0
+    for step in range(20):
+        before = task.rb_forces[:, task.object_rb_handles[0]].clone()
+        flagged = task.reset_buf.clone() != 0
+        task.step(torch.rand(n, nact, device=DEV) * 2 - 1)
+        untouched = torch.where(flagged.unsqueeze(-1), torch.zeros_like(before), before * consts[0])
+        sel += int((task.rb_forces[:, task.object_rb_handles[0]] != untouched).any(dim=1).sum())
+    rate = sel / (20.0 * n)
+    mean_p = float(task.random_force_prob.mean())
+    assert abs(rate - mean_p) < 0.03, (rate, mean_p)
+
+
+def test_force_scale_zero_launches_nothing():
+    task = tasks.make("AllegroHand", 256, DEV, seed=4)
+    task.step(torch.zeros(256, 16, device=DEV))
+    assert not (task.rb_forces != 0).any() and "rigid_body_force" not in task.sim.tensors

@@ -13,4 +13,4 @@ def test_allegro_oracle_matches_reference(variant):
     g = H.load_golden("allegro_" + variant)
     H.allegro_replay(g, oracle.allegro_pre_physics, oracle.allegro_post_physics,
                      to_buf=lambda a: np.ascontiguousarray(a).copy(), to_np=lambda a: a,
-                     zeros=lambda shape, dt: np.zeros(shape, dt))
+                     zeros=lambda shape, dt: np.zeros(shape, dt), force_fn=oracle.hand_random_forces)

@@ -13,4 +13,4 @@ def test_shadow_oracle_matches_reference(variant):
     g = H.load_golden("shadow_" + variant)
     H.shadow_replay(g, oracle.shadow_pre_physics, oracle.shadow_post_physics,
                     to_buf=lambda a: np.ascontiguousarray(a).copy(), to_np=lambda a: a,
-                    zeros=lambda shape, dt: np.zeros(shape, dt))
+                    zeros=lambda shape, dt: np.zeros(shape, dt), force_fn=oracle.hand_random_forces)
