@@ -771,6 +771,34 @@ typedef struct igx_episode_buffers {
 
 int igx_episode_stats_step(const igx_episode_buffers *b, int64_t n_envs, igx_stream_t stream);
 
+/* The episode_cumulative part of RLGPUAlgoObserver.process_infos (utils/rlgames_utils.py:159-174):
+ * for every key of infos['episode_cumulative']
+ *     cumulative[key] += value
+ *     for done_idx in done_indices (ascending):  window[key].append(cumulative[key][done_idx]);
+ *                                                cumulative[key][done_idx] = 0
+ * where window[key] is the reference's deque(maxlen=games_to_track): here a ring of games_to_track
+ * floats per key; finished episode number i (counted from the last time the caller zeroed the
+ * workspace) sits at ring position i % games_to_track, so the valid entries, oldest first, are
+ * positions (total - min(total, G)) .. (total - 1), each modulo G.  No nonzero(), no .item():
+ * after_print_stats (:200-206) reads the ring and the header once per epoch.
+ * workspace: IGX_EPISODE_WINDOW_WORKSPACE_BYTES(n_envs), 16-byte aligned, zeroed once by the caller;
+ * it starts with {uint64 finished_total; uint64 base; uint64 last_count; uint64 pad}. */
+#define IGX_EPISODE_WINDOW_MAX_KEYS 16
+#define IGX_EPISODE_WINDOW_HEADER_BYTES 32
+#define IGX_EPISODE_WINDOW_WORKSPACE_BYTES(n_envs) (32 + 16 * ((((int64_t)(n_envs) + 1023) / 1024 + 3) / 4))
+typedef struct igx_episode_window {
+    const int64_t *done;        /* [N] the reset flags returned by step() */
+    int32_t num_keys;
+    int32_t reserved;
+    int64_t games_to_track;     /* G: ring length per key */
+    const float *values[IGX_EPISODE_WINDOW_MAX_KEYS];   /* [N] per key: this step's infos['episode_cumulative'][key] */
+    float *cumulative[IGX_EPISODE_WINDOW_MAX_KEYS];     /* [N] per key, in/out */
+    float *window;              /* [num_keys, G] rings */
+    void *workspace;
+} igx_episode_window;
+
+int igx_episode_window_step(const igx_episode_window *w, int64_t n_envs, igx_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * torch_jit_utils math, one batched call per reference function
  * (utils/torch_jit_utils.py).  Quaternions are [n,4] xyzw, vectors [n,3],

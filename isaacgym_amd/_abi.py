@@ -256,6 +256,20 @@ class EpisodeBuffers(_Struct):
     _fields_ = [("rew", ptr), ("done", ptr), ("current_rewards", ptr), ("current_lengths", ptr), ("workspace", ptr)]
 
 
+IGX_EPISODE_WINDOW_MAX_KEYS = 16
+IGX_EPISODE_WINDOW_HEADER_BYTES = 32
+
+
+def IGX_EPISODE_WINDOW_WORKSPACE_BYTES(n):
+    return 32 + 16 * (((int(n) + 1023) // 1024 + 3) // 4)
+
+
+class EpisodeWindow(_Struct):
+    _fields_ = [("done", ptr), ("num_keys", i32), ("reserved", i32), ("games_to_track", i64),
+                ("values", ptr * IGX_EPISODE_WINDOW_MAX_KEYS), ("cumulative", ptr * IGX_EPISODE_WINDOW_MAX_KEYS),
+                ("window", ptr), ("workspace", ptr)]
+
+
 def make_buffers(cls, arrays, ptr_of):
     """Build a *Buffers struct from a name->array mapping.
 

@@ -53,6 +53,7 @@ SYMBOLS.update({
     "igx_quantile_f64": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
 })
 SYMBOLS["igx_episode_stats_step"] = (C.c_int, [_P, C.c_int64, _P])
+SYMBOLS["igx_episode_window_step"] = (C.c_int, [_P, C.c_int64, _P])
 SYMBOLS["igx_hand_random_forces"] = (C.c_int, [_P, C.c_int64, _P])
 # trajectory recorder
 SYMBOLS.update({

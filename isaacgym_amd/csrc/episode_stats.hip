@@ -129,9 +129,177 @@ __global__ __launch_bounds__(1024) void episode_reduce_kernel(EpisodeRecord *ws,
     }
 }
 
+// ---- windows of finished-episode values (RLGPUAlgoObserver.process_infos, utils/rlgames_utils.py:159-174) ----
+// Per key: cumulative[e] += value[e]; every done environment, in ascending environment order, appends its
+// cumulative value to a ring of the last G finished episodes (the reference's deque(maxlen=games_to_track))
+// and restarts from zero.  The ascending order needs each done environment's rank among this step's done
+// environments: a count per block of 1024 environments, an exclusive scan of the counts by one workgroup,
+// then the apply pass.
+struct WindowHeader {
+    unsigned long long finished_total;  // episodes appended since the caller zeroed the workspace
+    unsigned long long base;            // finished_total before this step (ring position of this step's rank 0)
+    unsigned long long last_count;      // done environments of this step
+    unsigned long long pad;
+};
+static_assert(sizeof(WindowHeader) == IGX_EPISODE_WINDOW_HEADER_BYTES, "header size is part of the ABI");
+
+__device__ __forceinline__ int done_count4(const int64_t *done, int64_t e0, int64_t n, bool vec, int (&d)[4])
+{
+    using v2l = long long __attribute__((ext_vector_type(2)));
+    if (vec && e0 + 3 < n) {
+        const v2l d0 = *reinterpret_cast<const v2l *>(done + e0);
+        const v2l d1 = *(reinterpret_cast<const v2l *>(done + e0) + 1);
+        d[0] = d0.x != 0; d[1] = d0.y != 0; d[2] = d1.x != 0; d[3] = d1.y != 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = (e0 + k < n) ? (done[e0 + k] != 0) : 0;
+    }
+    return d[0] + d[1] + d[2] + d[3];
+}
+
+// exclusive prefix of `c` over the 256 threads of the block; `total` = the block's sum
+__device__ __forceinline__ int block_exclusive_scan(int c, int &total)
+{
+    __shared__ int s_wave[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) before += i < w ? s_wave[i] : 0;
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return before + incl - c;
+}
+
+__global__ __launch_bounds__(256) void window_count_kernel(const int64_t *__restrict__ done, int64_t n, uint32_t *counts, bool vec)
+{
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    int d[4];
+    int c = e0 < n ? done_count4(done, e0, n, vec, d) : 0;
+    int total;
+    block_exclusive_scan(c, total);
+    if (threadIdx.x == 0) counts[blockIdx.x] = (uint32_t)total;
+}
+
+// one workgroup: counts -> exclusive offsets (in place), header updated
+__global__ __launch_bounds__(1024) void window_scan_kernel(WindowHeader *h, uint32_t *counts, int64_t num_blocks)
+{
+    __shared__ uint32_t s[1024];
+    __shared__ unsigned long long s_carry;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < num_blocks; i0 += 1024) {
+        const int64_t i = i0 + t;
+        const uint32_t c = i < num_blocks ? counts[i] : 0;
+        s[t] = c;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            const uint32_t add = t >= off ? s[t - off] : 0;
+            __syncthreads();
+            s[t] += add;
+            __syncthreads();
+        }
+        const unsigned long long carry = s_carry;
+        if (i < num_blocks) counts[i] = (uint32_t)(carry + s[t] - c);
+        __syncthreads();
+        if (t == 1023) s_carry = carry + s[1023];
+        __syncthreads();
+    }
+    if (t == 0) {
+        h->base = h->finished_total;
+        h->last_count = s_carry;
+        h->finished_total += s_carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void window_apply_kernel(const igx_episode_window w, int64_t n, const WindowHeader *h,
+                                                           const uint32_t *offsets, bool vec)
+{
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    int d[4] = {0, 0, 0, 0};
+    const int c = e0 < n ? done_count4(w.done, e0, n, vec, d) : 0;
+    int block_total;
+    const int before = block_exclusive_scan(c, block_total);
+    if (e0 >= n) return;
+    const unsigned long long base = h->base, total = h->last_count;
+    const unsigned long long G = (unsigned long long)w.games_to_track;
+    const unsigned long long first_kept = total > G ? total - G : 0;  // deque(maxlen=G): only the last G of a step survive
+    const unsigned long long rank0 = (unsigned long long)offsets[blockIdx.x] + (unsigned long long)before;
+    for (int k = 0; k < w.num_keys; ++k) {
+        const float *val = w.values[k];
+        float *cum = w.cumulative[k];
+        float *ring = w.window + (int64_t)k * w.games_to_track;
+        float a[4], v[4];
+        const bool v4 = vec && e0 + 3 < n && dev_aligned16(val) && dev_aligned16(cum);
+        if (v4) {
+            const v4f x = *reinterpret_cast<const v4f *>(val + e0), y = *reinterpret_cast<const v4f *>(cum + e0);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            a[0] = y.x; a[1] = y.y; a[2] = y.z; a[3] = y.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = e0 + i < n ? val[e0 + i] : 0.0f;
+                a[i] = e0 + i < n ? cum[e0 + i] : 0.0f;
+            }
+        }
+        unsigned long long rank = rank0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = a[i] + v[i];
+            if (d[i]) {
+                if (rank >= first_kept) ring[(base + rank) % G] = a[i];
+                a[i] = 0.0f;
+                ++rank;
+            }
+        }
+        if (v4) {
+            *reinterpret_cast<v4f *>(cum + e0) = v4f{a[0], a[1], a[2], a[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (e0 + i < n) cum[e0 + i] = a[i];
+        }
+    }
+}
+
 }  // namespace igx
 
 using namespace igx;
+
+extern "C" int igx_episode_window_step(const igx_episode_window *w, int64_t n_envs, igx_stream_t stream)
+{
+    const char *who = "igx_episode_window_step";
+    if (!w) return fail(IGX_E_NULL, "%s: argument struct is NULL", who);
+    if (n_envs < 0 || n_envs > ((int64_t)1 << 38)) return fail(IGX_E_SIZE, "%s: n_envs out of range", who);
+    if (w->num_keys < 0 || w->num_keys > IGX_EPISODE_WINDOW_MAX_KEYS)
+        return fail(IGX_E_PARAM, "%s: num_keys %d outside [0, %d]", who, w->num_keys, IGX_EPISODE_WINDOW_MAX_KEYS);
+    if (w->games_to_track < 1) return fail(IGX_E_PARAM, "%s: games_to_track must be >= 1", who);
+    if (n_envs == 0) return IGX_OK;
+    if (!w->done || !w->workspace || (w->num_keys > 0 && !w->window)) return fail(IGX_E_NULL, "%s: done / window / workspace is NULL", who);
+    for (int k = 0; k < w->num_keys; ++k)
+        if (!w->values[k] || !w->cumulative[k]) return fail(IGX_E_NULL, "%s: values / cumulative of key %d is NULL", who, k);
+    if (!aligned16(w->workspace)) return fail(IGX_E_ALIGN, "%s: workspace must be 16-byte aligned", who);
+    const int64_t blocks = (n_envs + 1023) / 1024;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WindowHeader *h = static_cast<WindowHeader *>(w->workspace);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(h + 1);
+    const bool vec = aligned16(w->done);
+    hipLaunchKernelGGL(window_count_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w->done, n_envs, counts, vec);
+    int rc = launch_status(who);
+    if (rc != IGX_OK) return rc;
+    hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(1024), 0, s, h, counts, blocks);
+    rc = launch_status(who);
+    if (rc != IGX_OK) return rc;
+    hipLaunchKernelGGL(window_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *w, n_envs, h, counts, vec);
+    return launch_status(who);
+}
 
 extern "C" int igx_episode_stats_step(const igx_episode_buffers *b, int64_t n_envs, igx_stream_t stream)
 {

@@ -1821,7 +1821,130 @@ def gen_episode_stats(seed=31, N=777, T=6):
     print("episode_stats.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()))
 
 
-GENERATORS = {"hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+def gen_observer(seed=41, N=333, H=5, EPOCHS=4, G=48):
+    """Episode statistics from the reference's own code: CommonAgent.play_steps (learning/common_agent.py:250-310)
+    runs its loop - current_rewards / current_lengths bookkeeping, game_rewards.update(...),
+    algo_observer.process_infos(infos, done_indices) - with the reference's RLGPUAlgoObserver
+    (utils/rlgames_utils.py:132-211) attached, and after_print_stats once per epoch.  The agent is the
+    reference class without its constructor; environment, policy, critic and experience buffer are
+    placeholders; what game_rewards / game_lengths receive and what the observer writes is recorded."""
+    from unittest import mock
+    ref_shim.install_learning_stubs()
+    ru = ref_shim.load("isaacgymenvs.utils.rlgames_utils")
+    ca = ref_shim.load("isaacgymenvs.learning.common_agent")
+    g = torch.Generator().manual_seed(seed)
+
+    class Meter:  # records what rl_games' AverageMeter.update would be given
+        def __init__(self):
+            self.calls = []
+
+        def update(self, values):
+            self.calls.append(values.reshape(-1).clone())
+
+    class Writer:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append((tag, float(value), float(step)))
+
+    class Agent(ca.CommonAgent):
+        def __init__(self):
+            pass
+
+        def set_eval(self):
+            pass
+
+        def _env_reset_done(self):
+            return {"obs": torch.zeros(N, 1)}, torch.zeros(0, dtype=torch.long)
+
+        def get_action_values(self, obs):
+            return {"actions": torch.zeros(N, 1)}
+
+        def _eval_critic(self, obs):
+            return torch.zeros(N, 1)
+
+        def discount_values(self, *a):
+            return mock.MagicMock()
+
+        def env_step(self, actions):
+            return self._feed.pop(0)
+
+    a = Agent()
+    a.update_list, a.horizon_length, a.use_action_masks, a.has_central_value = [], H, False, False
+    a.experience_buffer = mock.MagicMock()
+    a.rewards_shaper = lambda r: r
+    a.num_agents, a.batch_size, a.tensor_list = 1, N * H, []
+    a.current_rewards = torch.zeros(N, 1)
+    a.current_lengths = torch.zeros(N)
+    a.game_rewards, a.game_lengths = Meter(), Meter()
+    a.games_to_track, a.device = G, "cpu"
+    a.writer = Writer()
+    obs = ru.RLGPUAlgoObserver()
+    obs.after_init(a)
+    a.algo_observer = obs
+
+    keys = ("successes", "energy")
+    rec = {k: [] for k in ("rew", "dones", "cum_successes", "cum_energy", "ep_level", "ep_bonus", "cons", "current_rewards",
+                           "current_lengths", "acc_successes", "acc_energy", "n_done", "sum_reward", "sum_length",
+                           "mean_reward", "mean_length")}
+    windows, writes = [], []
+    for epoch in range(EPOCHS):
+        feed = []
+        for t in range(H):
+            rewards = torch.randn(N, 1, generator=g) * 3.0
+            p_done = 0.5 if (epoch == 1 and t == 2) else 0.07   # one step finishes more episodes than the window holds
+            dones = (torch.rand(N, generator=g) < p_done).to(torch.uint8)
+            if epoch == 2:
+                dones.zero_()  # an epoch without a finished episode: nothing new is logged
+            infos = {"terminate": torch.zeros(N), "consecutive_successes": torch.rand((), generator=g),
+                     "episode": {"level": torch.rand((), generator=g), "bonus": torch.rand(3, generator=g)},
+                     "episode_cumulative": {"successes": (torch.rand(N, generator=g) < 0.3).float(),
+                                            "energy": torch.randn(N, generator=g)},
+                     "scalars": {"lr": 0.25 * (epoch + 1)}, "tensor_info": torch.zeros(N)}
+            feed.append(({"obs": torch.zeros(N, 1)}, rewards, dones, infos))
+            rec["rew"].append(rewards.squeeze(1).numpy().copy())
+            rec["dones"].append(dones.numpy().astype(np.int64))
+            rec["cum_successes"].append(infos["episode_cumulative"]["successes"].numpy().copy())
+            rec["cum_energy"].append(infos["episode_cumulative"]["energy"].numpy().copy())
+            rec["ep_level"].append(infos["episode"]["level"].numpy().copy())
+            rec["ep_bonus"].append(infos["episode"]["bonus"].numpy().copy())
+            rec["cons"].append(infos["consecutive_successes"].numpy().copy())
+        a._feed = feed
+        n_before = len(a.game_rewards.calls)
+
+        # per-step state: hook the observer (the reference calls it once per step, last thing but the masking)
+        real = obs.process_infos
+
+        def spy(infos, done_indices, _real=real):
+            _real(infos, done_indices)
+            rec["acc_successes"].append(obs.episode_cumulative["successes"].numpy().copy())
+            rec["acc_energy"].append(obs.episode_cumulative["energy"].numpy().copy())
+        obs.process_infos = spy
+        a.play_steps()
+        obs.process_infos = real
+        for vr, vl in zip(a.game_rewards.calls[n_before:], a.game_lengths.calls[n_before:]):
+            rec["n_done"].append(np.int64(vr.numel()))
+            rec["sum_reward"].append(vr.double().sum().numpy())
+            rec["sum_length"].append(vl.double().sum().numpy())
+            rec["mean_reward"].append(vr.mean().numpy() if vr.numel() else np.float32("nan"))
+            rec["mean_length"].append(vl.mean().numpy() if vl.numel() else np.float32("nan"))
+        # the agent masks after the observer ran: state after the whole step is only visible per epoch
+        rec["current_rewards"].append(a.current_rewards.squeeze(1).numpy().copy())
+        rec["current_lengths"].append(a.current_lengths.numpy().copy())
+        windows.append({k: [float(x) for x in obs.episode_cumulative_avg.get(k, [])] for k in keys})
+        a.writer.rows = []
+        obs.after_print_stats(frame=(epoch + 1) * N * H, epoch_num=epoch + 1, total_time=1.5 * (epoch + 1))
+        writes.append(list(a.writer.rows))
+    res = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
+    res["meta"] = _meta(task="Observer", N=N, H=H, EPOCHS=EPOCHS, G=G, seed=seed, keys=list(keys), windows=windows,
+                        writes=writes)
+    np.savez_compressed(os.path.join(OUT, "observer.npz"), **res)
+    print("observer.npz", {k: v.shape for k, v in res.items() if hasattr(v, "shape")}, "done", int(res["n_done"].sum()),
+          "rows", [len(w) for w in writes])
+
+
+GENERATORS = {"observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

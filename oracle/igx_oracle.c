@@ -1879,3 +1879,31 @@ int orc_hand_random_forces(const igx_hand_forces *f, int64_t n)
     }
     return 0;
 }
+
+/* --------------------------------------------- windows of finished episodes --- */
+/* utils/rlgames_utils.py:159-174 (RLGPUAlgoObserver.process_infos): cumulative += value; every done
+ * environment, in index order, appends its cumulative value to a deque(maxlen=games_to_track) and is
+ * zeroed.  The deque is the ring described in igx.h; header = {finished_total, base, last_count, pad}. */
+int orc_episode_window_step(const igx_episode_window *w, int64_t n)
+{
+    if (!w || n < 0 || w->games_to_track < 1) return -1;
+    uint64_t *h = (uint64_t *)w->workspace;
+    const uint64_t G = (uint64_t)w->games_to_track;
+    uint64_t total = h[0];
+    h[1] = total;
+    for (int k = 0; k < w->num_keys; ++k)
+        for (int64_t e = 0; e < n; ++e) w->cumulative[k][e] = w->cumulative[k][e] + w->values[k][e];
+    uint64_t count = 0;
+    for (int64_t e = 0; e < n; ++e) {
+        if (w->done[e] == 0) continue;
+        for (int k = 0; k < w->num_keys; ++k) {
+            w->window[(uint64_t)k * G + (total % G)] = w->cumulative[k][e];  /* append: overwrites the oldest */
+            w->cumulative[k][e] = 0.0f;
+        }
+        ++total;
+        ++count;
+    }
+    h[0] = total;
+    h[2] = count;
+    return 0;
+}

@@ -389,3 +389,13 @@ def hand_random_forces(rb_forces, random_force_prob, reset, object_rb_handle, ob
                         force_scale=float(force_scale), decay=float(decay), log_prob_lo=float(log_prob_lo),
                         log_prob_hi=float(log_prob_hi), seed=int(seed), rng_offset=int(rng_offset))
     assert lib().orc_hand_random_forces(C.byref(s), C.c_int64(n)) == 0
+
+
+def episode_window_step(done, values, cumulative, window, workspace, games_to_track):
+    """CPU restatement of igx_episode_window_step (utils/rlgames_utils.py:159-174): values / cumulative are
+    lists of [N] float32 arrays (one per key), window is [num_keys, G] float32, workspace an int64 array."""
+    w = _abi.EpisodeWindow(done=_np_ptr(done), num_keys=len(values), games_to_track=int(games_to_track),
+                           window=_np_ptr(window), workspace=_np_ptr(workspace))
+    w.set("values", [_np_ptr(v) for v in values])
+    w.set("cumulative", [_np_ptr(c) for c in cumulative])
+    assert lib().orc_episode_window_step(C.byref(w), C.c_int64(done.shape[0])) == 0

@@ -111,3 +111,47 @@ if __name__ == "__main__":
               "isaacgymenvs.tasks.humanoid_amp", "isaacgymenvs.tasks.amp.utils_amp.motion_lib"):
         mod = load(m)
         print("ok", m, getattr(mod, "__file__", None))
+
+
+def install_learning_stubs():
+    """Enough of rl_games / tensorboardX (neither is in this image nor in the reference tree) for the
+    reference's own utils/rlgames_utils.py and learning/common_agent.py to be imported: empty base
+    classes and placeholder attributes only - none of the code under test lives in them.  The observer
+    (RLGPUAlgoObserver) and the agent loop (CommonAgent.play_steps) that then run are the reference's."""
+    install()
+    from unittest import mock
+
+    class _Base:
+        def __init__(self, *a, **k):
+            pass
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or _stub(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    placeholder = mock.MagicMock()
+    mod("rl_games")
+    mod("rl_games.common", env_configurations=placeholder, vecenv=mock.MagicMock(IVecEnv=_Base))
+    mod("rl_games.common.env_configurations", configurations={})
+    mod("rl_games.common.vecenv", IVecEnv=_Base)
+    mod("rl_games.common.algo_observer", AlgoObserver=_Base)
+    mod("rl_games.common.a2c_common", A2CBase=_Base, swap_and_flatten01=lambda x: x)
+    mod("rl_games.common.datasets", PPODataset=_Base)
+    mod("rl_games.common.schedulers")
+    mod("rl_games.algos_torch")
+    mod("rl_games.algos_torch.a2c_continuous", A2CAgent=_Base)
+    mod("rl_games.algos_torch.torch_ext")
+    mod("rl_games.algos_torch.central_value")
+    mod("rl_games.algos_torch.running_mean_std", RunningMeanStd=_Base)
+    for child in ("env_configurations", "vecenv", "algo_observer", "a2c_common", "datasets", "schedulers"):
+        setattr(sys.modules["rl_games.common"], child, sys.modules["rl_games.common." + child])
+    for child in ("a2c_continuous", "torch_ext", "central_value", "running_mean_std"):
+        setattr(sys.modules["rl_games.algos_torch"], child, sys.modules["rl_games.algos_torch." + child])
+    mod("tensorboardX", SummaryWriter=_Base)
+    sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+    sys.modules["gym.spaces"].Space = object  # appears in annotations only
+    sys.modules["isaacgymenvs.tasks"].isaacgym_task_map = {}
+    if "isaacgymenvs.learning" not in sys.modules:
+        _ns("isaacgymenvs.learning", os.path.join(IGE, "learning"))

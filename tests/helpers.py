@@ -557,3 +557,60 @@ def him_replay(g, step_fn, to_buf, to_np, zeros):
         assert bit_equal_fraction(to_np(pot), g["potentials"][t]) == 1.0, what + "potentials"
         assert bit_equal_fraction(to_np(prev), g["prev_potentials"][t]) == 1.0, what + "prev_potentials"
         assert_close(to_np(bufs["rew"]), g["rew"][t], what=what + "rew")  # sums of 63 / 66 terms, exp
+
+
+# ---- episode statistics: the recording of the reference's agent loop + observer (observer.npz) ------
+class RecordingWriter:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, value, step):
+        self.rows.append((tag, float(value), float(step)))
+
+
+def observer_replay(g, observer, stats_step, to_tensor, to_np, sum_rtol=0.0):
+    """Feed the recorded steps to `observer` (an isaacgym_amd RLGPUAlgoObserver, after_init not yet called)
+    and to `stats_step(rew, dones) -> (n_done, sum_reward, sum_length, current_rewards, current_lengths)`;
+    compare with what the reference's CommonAgent.play_steps + RLGPUAlgoObserver left behind: the
+    per-environment accumulators bit for bit after every step, the values game_rewards / game_lengths were
+    given, and every writer.add_scalar row of every epoch."""
+    import types
+    import torch
+    m = g["meta"]
+    N, Hz, EPOCHS, G = m["N"], m["H"], m["EPOCHS"], m["G"]
+    algo = types.SimpleNamespace(games_to_track=G, device=to_tensor(np.zeros(1, np.float32)).device, writer=RecordingWriter())
+    observer.after_init(algo)
+    t = 0
+    for epoch in range(EPOCHS):
+        for _ in range(Hz):
+            dones = to_tensor(g["dones"][t])
+            infos = {"terminate": to_tensor(np.zeros(N, np.float32)), "consecutive_successes": to_tensor(g["cons"][t]),
+                     "episode": {"level": to_tensor(g["ep_level"][t]), "bonus": to_tensor(g["ep_bonus"][t])},
+                     "episode_cumulative": {"successes": to_tensor(g["cum_successes"][t]),
+                                            "energy": to_tensor(g["cum_energy"][t])},
+                     "scalars": {"lr": 0.25 * (epoch + 1)}, "tensor_info": to_tensor(np.zeros(N, np.float32))}
+            n, sr, sl, cr, cl = stats_step(to_tensor(g["rew"][t]), dones)
+            observer.process_infos_flags(infos, dones)
+            what = "step %d " % t
+            assert n == int(g["n_done"][t]), what + "n_done"
+            # the finished episodes' rewards: exact values, summed here in double
+            # (the device adds them in another order: sum_rtol)
+            assert abs(sr - float(g["sum_reward"][t])) <= sum_rtol * max(1.0, abs(float(g["sum_reward"][t]))), what + "sum_reward"
+            assert sl == float(g["sum_length"][t]), what + "sum_length"
+            for key in ("successes", "energy"):
+                got = to_np(observer.episode_cumulative[key])
+                assert np.array_equal(got.view(np.uint32), g["acc_" + key][t].view(np.uint32)), what + "accumulator " + key
+            t += 1
+        assert np.array_equal(to_np(cr).view(np.uint32), g["current_rewards"][epoch].view(np.uint32)), "current_rewards"
+        assert np.array_equal(to_np(cl).view(np.uint32), g["current_lengths"][epoch].view(np.uint32)), "current_lengths"
+        win, _ = observer.windows()
+        for key in ("successes", "energy"):
+            ref = np.asarray(m["windows"][epoch][key], np.float64)
+            assert np.array_equal(win[key], ref), "window %s epoch %d" % (key, epoch)  # same values, same (deque) order
+        algo.writer.rows = []
+        observer.after_print_stats(frame=(epoch + 1) * N * Hz, epoch_num=epoch + 1, total_time=1.5 * (epoch + 1))
+        ref_rows = [tuple(r) for r in m["writes"][epoch]]
+        assert [r[0] for r in algo.writer.rows] == [r[0] for r in ref_rows], "tags epoch %d" % epoch
+        for (tag, v, s), (_, rv, rs) in zip(algo.writer.rows, ref_rows):
+            assert s == rs, tag
+            assert v == rv or abs(v - rv) <= 1e-6 * max(1.0, abs(rv)), (tag, v, rv)  # float32 means of the same values

@@ -53,3 +53,74 @@ def test_episode_stats_vs_oracle(n):
     m = es.means()
     if tot[0]:
         np.testing.assert_allclose(m, (tot[1] / tot[0], tot[2] / tot[0]), rtol=1e-6, atol=1e-5)
+
+
+def test_observer_matches_the_reference_run():
+    """observer.npz: the reference's CommonAgent.play_steps + RLGPUAlgoObserver; here EpisodeStats and the
+    product's observer on the device (igx_episode_stats_step, igx_episode_window_step)."""
+    from isaacgym_amd.utils.rlgames_utils import RLGPUAlgoObserver
+    g = H.load_golden("observer")
+    es = EpisodeStats(g["meta"]["N"], DEV)
+
+    def stats_step(rew, dones):
+        es.step(rew, dones)
+        n, sr, sl = es.last_step()
+        return n, sr, sl, es.current_rewards, es.current_lengths
+
+    H.observer_replay(g, RLGPUAlgoObserver(), stats_step, to_tensor=lambda a: torch.tensor(np.asarray(a)).to(DEV),
+                      to_np=lambda t: t.cpu().numpy(), sum_rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,G,p", [(1, 4, 1.0), (1023, 100, 0.3), (1024, 7, 0.9), (70001, 128, 0.01), (1 << 20, 1000, 0.02)])
+def test_episode_window_vs_oracle(n, G, p):
+    """igx_episode_window_step against the CPU checker: accumulators, rings and counters bit for bit, with
+    steps that finish fewer and more episodes than the window holds, and the index-based entry point."""
+    import types
+    from isaacgym_amd.utils.rlgames_utils import RLGPUAlgoObserver
+    obs = RLGPUAlgoObserver()
+    obs.after_init(types.SimpleNamespace(games_to_track=G, device=DEV, writer=H.RecordingWriter()))
+    gen = torch.Generator().manual_seed(n + G)
+    keys = ["a", "b", "c"]
+    cum = [np.zeros(n, np.float32) for _ in keys]
+    win, ws = np.zeros((len(keys), G), np.float32), np.zeros(8 + (n + 1023) // 1024, np.int64)
+    for t in range(4):
+        vals = [torch.randn(n, generator=gen) for _ in keys]
+        done = (torch.rand(n, generator=gen) < (p if t != 2 else 0.0)).to(torch.int64)
+        infos = {"episode_cumulative": {k: v.to(DEV) for k, v in zip(keys, vals)}}
+        if t == 1:  # the reference's signature: indices from nonzero()
+            obs.process_infos(infos, done.nonzero(as_tuple=False).to(DEV))
+        else:
+            obs.process_infos_flags(infos, done.to(DEV))
+        oracle.episode_window_step(done.numpy(), [v.numpy() for v in vals], cum, win, ws, G)
+        for j, k in enumerate(keys):
+            assert np.array_equal(obs.episode_cumulative[k].cpu().numpy().view(np.uint32), cum[j].view(np.uint32)), (k, t)
+        assert obs._ws[:3].cpu().tolist() == ws[:3].tolist()
+        total = int(ws[0])
+        valid = [(i % G) for i in range(max(total - G, 0), total)]  # ring slots that hold an episode
+        assert np.array_equal(obs._window.cpu().numpy()[:, valid].view(np.uint32), win[:, valid].view(np.uint32)), t
+
+
+def test_game_stats_windowed_meters():
+    """GameStats: per-step records replayed into rl_games-style windowed means once per horizon; equal to
+    updating the meters with current_rewards[done_indices] every step (learning/common_agent.py:284-296)."""
+    from isaacgym_amd.utils.rlgames_utils import AverageMeter, GameStats
+    n = 5000
+    gs = GameStats(n, DEV, games_to_track=100, horizon=4)
+    ref_r, ref_l = AverageMeter(100), AverageMeter(100)
+    cr, cl = torch.zeros(n), torch.zeros(n)
+    gen = torch.Generator().manual_seed(5)
+    for t in range(10):
+        rew = torch.randn(n, generator=gen)
+        dones = (torch.rand(n, generator=gen) < 0.004).to(torch.int64)
+        gs.step(rew.to(DEV), dones.to(DEV))
+        cr += rew
+        cl += 1
+        idx = dones.nonzero(as_tuple=False).squeeze(-1)
+        ref_r.update(cr[idx])
+        ref_l.update(cl[idx])
+        cr *= 1.0 - dones.float()
+        cl *= 1.0 - dones.float()
+    gs.flush()
+    assert len(gs.game_rewards) == len(ref_r) and len(gs.game_lengths) == len(ref_l)
+    np.testing.assert_allclose(gs.game_rewards.get_mean(), ref_r.get_mean(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gs.game_lengths.get_mean(), ref_l.get_mean(), rtol=1e-6)
