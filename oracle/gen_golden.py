@@ -455,7 +455,8 @@ def gen_ant_imitate(seed=41, N=257, T=7, F=9):
             "potentials0": t.potentials.numpy().copy(), "target_pose_idx0": t.target_pose_idx.numpy().copy(),
             "initial_root_states": t.initial_root_states.numpy().copy(),
             "initial_dof_pos": t.initial_dof_pos.numpy().copy(),
-            "dof_limits_lower": lo.numpy().copy(), "dof_limits_upper": hi.numpy().copy(), "motion": motion}
+            "dof_limits_lower": lo.numpy().copy(), "dof_limits_upper": hi.numpy().copy(), "motion": motion,
+            "targets": t.targets[0].numpy().copy(), "inv_start_rot": t.inv_start_rot[0].numpy().copy()}
     torch.manual_seed(seed + 100)
     for step in range(T):
         _loco_inputs(t, N, D, S, g, 0.55, 0.1, False)

@@ -14,7 +14,8 @@ import numpy as np
 from isaacgym_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libigx_oracle.so")
+# IGX_ORACLE_SO: another build of the same source (the sanitizer build of `make -C oracle asan`)
+_SO = os.environ.get("IGX_ORACLE_SO") or os.path.join(_HERE, "libigx_oracle.so")
 _lib = None
 
 

@@ -78,8 +78,7 @@ def loco_params(meta, g, seed=0, rng_offset=0):
         joints_at_limit_cost_scale=meta["joints_at_limit_cost_scale"],
         termination_height=meta["termination_height"], death_cost=meta["death_cost"],
         max_episode_length_m1=float(meta["max_episode_length"] - 1),
-        targets=g["targets"] if "targets" in g else [1000.0, 0.0, 0.0],
-        inv_start_rot=g["inv_start_rot"] if "inv_start_rot" in g else [-0.0, -0.0, -0.0, 1.0],
+        targets=g["targets"], inv_start_rot=g["inv_start_rot"],
         basis_vec0=[1.0, 0.0, 0.0], basis_vec1=[0.0, 0.0, 1.0],
         dof_limits_lower=g["dof_limits_lower"], dof_limits_upper=g["dof_limits_upper"],
         seed=seed, rng_offset=rng_offset)

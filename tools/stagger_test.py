@@ -56,4 +56,5 @@ def main():
         del carved, arenas
 
 
-main()
+if __name__ == "__main__":
+    main()
