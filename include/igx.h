@@ -65,6 +65,9 @@ typedef struct igx_cartpole_params {
     const uint64_t *rng_offset_dev; /* optional device-resident counter added to rng_offset when the kernel draws:
                                      a recorded HIP graph replays the same argument values, the counter (advanced
                                      on the stream between replays) gives every replay fresh draws; NULL = 0 */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_cartpole_params;
 
 typedef struct igx_cartpole_buffers {
@@ -119,6 +122,9 @@ typedef struct igx_loco_params {
     uint64_t seed;
     uint64_t rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_loco_params;
 
 typedef struct igx_loco_buffers {
@@ -245,6 +251,9 @@ typedef struct igx_humanoid_imitate_params {
     uint64_t seed;
     uint64_t rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_humanoid_imitate_params;
 
 typedef struct igx_humanoid_imitate_buffers {
@@ -310,6 +319,9 @@ typedef struct igx_allegro_params {
     float clip_obs;               /* env.clipObservations (+inf copies); read only with obs_clamped / states_clamped */
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_allegro_params;
 
 /* scratch for the cross-environment reduction: 16-byte records - the total, then one per tile of
@@ -420,6 +432,9 @@ typedef struct igx_shadow_params {
     float clip_obs;                    /* as in igx_allegro_params */
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_shadow_params;
 
 typedef struct igx_shadow_buffers {
@@ -488,6 +503,9 @@ typedef struct igx_hand_forces {
     int32_t reserved;
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_hand_forces;
 
 int igx_hand_random_forces(const igx_hand_forces *f, int64_t n_envs, igx_stream_t stream);
@@ -562,6 +580,9 @@ typedef struct igx_motion_sampler {
     float ref_init_prob;            /* 1: every reset takes a reference state */
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
+    int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
+                                       environment index in the Philox counter only, so that a shard draws what the
+                                       unsharded run draws for the same environments */
 } igx_motion_sampler;
 int igx_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampler *s, const int64_t *reset, int64_t n,
                               int64_t *env_ids, int64_t *motion_ids, double *motion_times, int64_t *default_env_ids,

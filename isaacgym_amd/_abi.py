@@ -44,7 +44,7 @@ class _Struct(C.Structure):
 class CartpoleParams(_Struct):
     _fields_ = [("reset_dist", f32), ("max_episode_length_m1", f32),
                 ("reward_variant", i32), ("reserved", i32),
-                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class CartpoleBuffers(_Struct):
@@ -67,7 +67,7 @@ class LocoParams(_Struct):
                 ("dof_limits_upper", f32 * IGX_MAX_DOF),
                 ("motor_efforts", f32 * IGX_MAX_DOF),
                 ("max_motor_effort", f32), ("clip_obs", f32), ("reserved", i32),
-                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class LocoBuffers(_Struct):
@@ -100,7 +100,7 @@ class AllegroParams(_Struct):
                 ("dof_speed_scale_dt", f32),
                 ("goal_displacement", f32 * 3),
                 ("dof_lower", f32 * IGX_ALLEGRO_DOF), ("dof_upper", f32 * IGX_ALLEGRO_DOF),
-                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class AllegroBuffers(_Struct):
@@ -134,7 +134,7 @@ class ShadowParams(_Struct):
                 ("goal_displacement", f32 * 3), ("num_bodies", i32),
                 ("dof_lower", f32 * IGX_SHADOW_DOF), ("dof_upper", f32 * IGX_SHADOW_DOF),
                 ("actuated_dof_indices", i32 * IGX_SHADOW_ACTIONS), ("fingertip_handles", i32 * IGX_SHADOW_FINGERTIPS),
-                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class ShadowBuffers(_Struct):
@@ -155,7 +155,7 @@ class HandForces(_Struct):
     _fields_ = [("rb_forces", ptr), ("random_force_prob", ptr), ("reset", ptr), ("rand", ptr),
                 ("num_bodies", i32), ("object_rb_handle", i32), ("object_rb_mass", f32), ("force_scale", f32),
                 ("decay", f32), ("log_prob_lo", f32), ("log_prob_hi", f32), ("reserved", i32),
-                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 IGX_AMP_NUM_BODIES = 15
@@ -173,7 +173,7 @@ class MotionTables(_Struct):
 
 class MotionSampler(_Struct):
     _fields_ = [("cdf", ptr), ("random_time", i32), ("ref_init_prob", f32), ("seed", u64), ("rng_offset", u64),
-                ("rng_offset_dev", ptr)]
+                ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class MotionStateOut(_Struct):
@@ -227,7 +227,7 @@ class HumanoidImitateParams(_Struct):
                 ("termination_height", f32), ("termination_radius_sq", f32), ("max_episode_length_m1", f32),
                 ("reserved", i32), ("targets", f32 * 3), ("clip_obs", f32),
                 ("dof_limits_lower", f32 * (IGX_HIM_DOF + 1)), ("dof_limits_upper", f32 * (IGX_HIM_DOF + 1)),
-                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr)]
+                ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class HumanoidImitateBuffers(_Struct):

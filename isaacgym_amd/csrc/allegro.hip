@@ -51,7 +51,7 @@ __device__ __forceinline__ float allegro_draw(const igx_allegro_params &p, const
         u = b.rand[e * IGX_ALLEGRO_RAND_PER_ENV + j];
     } else {
         float q[4];
-        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, j >> 2, q);
+        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, j >> 2, q);
         const int a = j & 3;
         u = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
     }

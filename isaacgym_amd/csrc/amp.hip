@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void motion_sample_flagged_kernel(const igx_mo
     double time = 0.0;
     if (reset[e] != 0) {
         float u[4];
-        philox_uniform4(s.seed, rng_offset_of(s.rng_offset, s.rng_offset_dev), e, 0, u);
+        philox_uniform4(s.seed, rng_offset_of(s.rng_offset, s.rng_offset_dev), e + s.env_offset, 0, u);
         if (u[2] < s.ref_init_prob) {
             const double pick = (double)u[0];
             id = 0;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void cartpole_step_kernel(const igx_cartpole_p
             const float4 r = reinterpret_cast<const float4 *>(b.rand)[e];
             u[0] = r.x; u[1] = r.y; u[2] = r.z; u[3] = r.w;
         } else {
-            philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, 0, u);
+            philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, 0, u);
         }
         ds.x = 0.9f * (u[0] - 0.5f);
         ds.z = 0.9f * (u[1] - 0.5f);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void cartpole_reset_kernel(const igx_cartpole_
         const float4 r = reinterpret_cast<const float4 *>(b.rand)[e];
         u[0] = r.x; u[1] = r.y; u[2] = r.z; u[3] = r.w;
     } else {
-        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, 0, u);
+        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, 0, u);
     }
     float4 ds;
     ds.x = 0.9f * (u[0] - 0.5f);

@@ -30,8 +30,8 @@ __device__ __forceinline__ ForceDraws force_draws(const igx_hand_forces &f, int6
     } else {
         float u[4], v[4];
         const uint64_t off = rng_offset_of(f.rng_offset, f.rng_offset_dev);
-        philox_uniform4(f.seed, off, e, 0, u);
-        philox_uniform4(f.seed, off, e, 1, v);
+        philox_uniform4(f.seed, off, e + f.env_offset, 0, u);
+        philox_uniform4(f.seed, off, e + f.env_offset, 1, v);
         d.u_prob = u[0]; d.u_sel = u[1];
         // Box-Muller on (u2, u3) and (v0, v1): three of the four normals
         const float r0 = sqrtf(-2.0f * logf(1.0f - u[2])), a0 = 6.2831855f * u[3];

@@ -146,10 +146,10 @@ __global__ __launch_bounds__(WAVE) void humanoid_imitate_kernel(const igx_humano
                 uv = b.rand[e * (2 * HD) + HD + j];
             } else {
                 float q[4];
-                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, j >> 2, q);
+                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, j >> 2, q);
                 const int a = j & 3;
                 up = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
-                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, (HD + j) >> 2, q);
+                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, (HD + j) >> 2, q);
                 const int c = (HD + j) & 3;
                 uv = c == 0 ? q[0] : c == 1 ? q[1] : c == 2 ? q[2] : q[3];
             }

@@ -87,10 +87,10 @@ __device__ __forceinline__ void reset_joints(const igx_loco_params &p, const igx
                 uv = b.rand[e * (2 * D) + D + j];
             } else {
                 float q[4];
-                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, j >> 2, q);
+                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, j >> 2, q);
                 const int a = j & 3;
                 up = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
-                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, (D + j) >> 2, q);
+                philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, (D + j) >> 2, q);
                 const int c = (D + j) & 3;
                 uv = c == 0 ? q[0] : c == 1 ? q[1] : c == 2 ? q[2] : q[3];
             }
@@ -452,10 +452,10 @@ __global__ __launch_bounds__(256) void loco_reset_kernel(const igx_loco_params p
         uv = b.rand[e * (2 * D) + D + j];
     } else {
         float q[4];
-        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, j >> 2, q);
+        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, j >> 2, q);
         const int a = j & 3;
         up = a == 0 ? q[0] : a == 1 ? q[1] : a == 2 ? q[2] : q[3];
-        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e, (D + j) >> 2, q);
+        philox_uniform4(p.seed, rng_offset_of(p.rng_offset, p.rng_offset_dev), e + p.env_offset, (D + j) >> 2, q);
         const int c = (D + j) & 3;
         uv = c == 0 ? q[0] : c == 1 ? q[1] : c == 2 ? q[2] : q[3];
     }

@@ -33,8 +33,10 @@ def env_shard(num_envs, rank, world_size):
 
 
 def shard_seed(seed, rank):
-    """Per-rank generator key: the in-kernel Philox counter is the *local* environment index,
-    so shards must not share a key."""
+    """A per-rank generator key, for shards that do not pass their `env_offset`.  The Philox counter is
+    (environment index + env_offset): shards that set `env_offset = env_shard(...)[0]` and share ONE seed draw
+    exactly what a single GPU would draw for the same environments; shards that leave env_offset at 0 need
+    different keys, or they would all draw the same numbers."""
     return (int(seed) ^ (int(rank) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
 
 

@@ -86,7 +86,7 @@ def hand_force_constants(force_decay, dt, force_decay_interval, force_prob_range
 
 
 def hand_random_forces(rb_forces, random_force_prob, reset, object_rb_handle, object_rb_mass, force_scale, decay,
-                       log_prob_lo, log_prob_hi, rand=None, seed=0, rng_offset=0, rng_offset_dev=None):
+                       log_prob_lo, log_prob_hi, rand=None, seed=0, rng_offset=0, rng_offset_dev=None, env_offset=0):
     """igx_hand_random_forces on rb_forces [N, B, 3]: zero + re-draw for flagged environments, decay, new object
     forces where the Bernoulli draw says so.  Call before the task's pre-physics kernel of the same step."""
     if rb_forces.dim() != 3 or rb_forces.shape[2] != 3:
@@ -103,7 +103,7 @@ def hand_random_forces(rb_forces, random_force_prob, reset, object_rb_handle, ob
                         num_bodies=int(nb), object_rb_handle=int(object_rb_handle), object_rb_mass=float(object_rb_mass),
                         force_scale=float(force_scale), decay=float(decay), log_prob_lo=float(log_prob_lo),
                         log_prob_hi=float(log_prob_hi), seed=int(seed), rng_offset=int(rng_offset),
-                        rng_offset_dev=rng_offset_dev)
+                        rng_offset_dev=rng_offset_dev, env_offset=int(env_offset))
     for t in (random_force_prob, reset) + ((rand,) if rand is not None else ()):
         if t.device != dev:
             raise ValueError("all tensors must live on %s" % dev)
@@ -171,7 +171,7 @@ def motion_state(tables, motion_ids, motion_times, out):
 
 
 def motion_sample_flagged(tables, cdf, reset, env_ids, motion_ids, motion_times, random_time=True, seed=0, rng_offset=0,
-                          rng_offset_dev=None, ref_init_prob=1.0, default_env_ids=None):
+                          rng_offset_dev=None, ref_init_prob=1.0, default_env_ids=None, env_offset=0):
     """Reference-state sampling for the environments whose reset flag is set, on the device (no nonzero(),
     no numpy): fills env_ids / motion_ids / motion_times [n]; environments without the flag get -1 / -1 / 0,
     which motion_state, motion_amp_obs and humanoid_amp_reset skip.  With ref_init_prob < 1 a flagged
@@ -179,7 +179,8 @@ def motion_sample_flagged(tables, cdf, reset, env_ids, motion_ids, motion_times,
     instead (stateInit Hybrid; 0 = stateInit Default)."""
     dev = reset.device
     s = _abi.MotionSampler(cdf=_lib.tensor_ptr(cdf, torch.float64), random_time=int(bool(random_time)), seed=int(seed),
-                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev, ref_init_prob=float(ref_init_prob))
+                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev, ref_init_prob=float(ref_init_prob),
+                           env_offset=int(env_offset))
     n = reset.shape[0]
     for t in (env_ids, motion_ids, motion_times) + ((default_env_ids,) if default_env_ids is not None else ()):
         if t.shape[0] != n:

@@ -16,12 +16,14 @@ as in the reference, so a seeded run draws the same (ids, times).
 Motion files: `.npz` with plain arrays (rotation [F,J,4] xyzw, root_translation
 [F,3], global_velocity [F,J,3], global_angular_velocity [F,J,3], parent_indices
 [J], local_translation [J,3], fps, is_local), the reference's own `.npy` (a
-pickled dict written by poselib's SkeletonMotion.to_file; loaded only with
-allow_pickle=True, i.e. for files the caller trusts), or a `.yaml` motion set
+pickled dict written by poselib's SkeletonMotion.to_file; read through an
+unpickler that resolves numpy arrays, dtypes, scalars and OrderedDict and
+nothing else - never through np.load(allow_pickle=True)), or a `.yaml` motion set
 (`motions: [{file, weight}, ...]`, paths relative to the yaml).
 """
 import ctypes as C
 import os
+import pickle
 
 import numpy as np
 import torch
@@ -119,7 +121,49 @@ class _Motion:
         self.global_root_angular_velocity = self.global_angular_velocity[:, 0]
 
 
+_NPY_GLOBALS = {  # everything a poselib motion file needs to be rebuilt: arrays, dtypes, scalars, ordered dicts
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"),
+}
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    """Unpickler that resolves only the globals in _NPY_GLOBALS: a file naming anything else (which is how a
+    pickle makes the loader call arbitrary code) is rejected before that object is looked up."""
+
+    def find_class(self, module, name):
+        if (module, name) not in _NPY_GLOBALS:
+            raise pickle.UnpicklingError("motion file refers to %s.%s, which a poselib motion does not need; "
+                                         "refusing to load it" % (module, name))
+        return super().find_class(module, name)
+
+
+def read_poselib_npy(path):
+    """The dict inside a poselib .npy (np.save of a Python dict = an object array holding one pickled dict,
+    poselib/core/backend/abstract.py:116-150), read without np.load(allow_pickle=True): the .npy header is
+    parsed here and the payload goes through _RestrictedUnpickler."""
+    with open(path, "rb") as fh:
+        version = np.lib.format.read_magic(fh)
+        if version == (1, 0):
+            shape, _, dtype = np.lib.format.read_array_header_1_0(fh)
+        elif version == (2, 0):
+            shape, _, dtype = np.lib.format.read_array_header_2_0(fh)
+        else:
+            raise ValueError("%s: unsupported .npy version %r" % (path, version))
+        if not dtype.hasobject or shape != ():
+            raise ValueError("%s is not a poselib motion (expected one pickled dict, found %s array of shape %s)"
+                             % (path, dtype, shape))
+        obj = _RestrictedUnpickler(fh).load()
+    d = obj.item() if isinstance(obj, np.ndarray) else obj
+    if not isinstance(d, dict):
+        raise ValueError("%s does not hold a dict" % path)
+    return d
+
+
 def load_motion_file(path, allow_pickle=False):
+    """.npz (plain arrays) or a poselib .npy.  `allow_pickle` is accepted for older callers and ignored:
+    a .npy is always read through the restricted unpickler, never through numpy's pickle loader."""
     ext = os.path.splitext(path)[1]
     if ext == ".npz":
         z = np.load(path, allow_pickle=False)
@@ -127,10 +171,7 @@ def load_motion_file(path, allow_pickle=False):
                        z["parent_indices"], z["local_translation"], float(z["fps"]),
                        bool(z["is_local"]) if "is_local" in z.files else True)
     if ext == ".npy":
-        if not allow_pickle:
-            raise ValueError("%s is a pickled poselib motion; pass allow_pickle=True for files you trust, "
-                             "or convert it to .npz with isaacgym_amd.tasks.amp.utils_amp.motion_lib.convert_npy" % path)
-        d = np.load(path, allow_pickle=True).item()
+        d = read_poselib_npy(path)
         tree = d["skeleton_tree"]
         return _Motion(d["rotation"]["arr"], d["root_translation"]["arr"], d["global_velocity"]["arr"],
                        d["global_angular_velocity"]["arr"], tree["parent_indices"]["arr"],
@@ -148,8 +189,8 @@ def save_motion_npz(path, m):
 
 
 def convert_npy(src, dst):
-    """Convert a trusted poselib .npy motion to the plain-array .npz format."""
-    save_motion_npz(dst, load_motion_file(src, allow_pickle=True))
+    """Convert a poselib .npy motion to the plain-array .npz format."""
+    save_motion_npz(dst, load_motion_file(src))
 
 
 class MotionLib:
@@ -244,8 +285,11 @@ class MotionLib:
             out_row_stride = _abi.IGX_AMP_OBS
         elif out_row_stride is None:
             raise ValueError("out_row_stride is required with out")
-        rows = None if out_rows is None else _lib.tensor_ptr(out_rows.to(dev), torch.int64)
-        keep = out_rows  # keep a reference alive across the async launch
+        # the converted copy (not only the caller's tensor) must outlive the asynchronous launch
+        rows_t = None if out_rows is None else out_rows.to(dev, torch.int64).contiguous()
+        if rows_t is not None and rows_t.shape[0] != n:
+            raise ValueError("out_rows must name one row per sample")
+        rows = None if rows_t is None else _lib.tensor_ptr(rows_t, torch.int64)
         with torch.cuda.device(dev):
             rc = _lib.lib().igx_motion_amp_obs(C.byref(self._tables), _lib.tensor_ptr(ids, torch.int64),
                                                _lib.tensor_ptr(times, torch.float64), C.c_int64(n),
@@ -253,7 +297,7 @@ class MotionLib:
                                                rows, C.c_int64(out_row_stride), C.c_int64(out_col_offset),
                                                _lib.current_stream(dev))
         _lib.check(rc)
-        del keep
+        self._last_rows = rows_t  # released when the next call replaces it: by then this launch has been enqueued
         return out
 
     # ---- loading ------------------------------------------------------------

@@ -36,6 +36,9 @@ class AntImitate(Ant):
                                 self.QUANTILE_THRESHOLD, self.DISTANCE_FLOOR, float(self.death_cost), n_total)
 
     def post_physics_step(self):
+        # ant_imitate.py reset_idx re-randomises like Ant's, i.e. on steps where some env is reset
+        if self.randomize and bool(self.reset_buf.any()):
+            self.apply_randomizations(self.randomization_params)
         world = distributed.world_size(self._group)
         if world == 1:
             ops.ant_imitate_step(self._params(), self._buffers(), self._imitate_args(self.num_envs), self.num_envs)

@@ -157,7 +157,13 @@ class VecTask:
         C.memmove(C.byref(p), C.byref(self._ptmpl), C.sizeof(p))
         p.rng_offset = self._draws
         p.rng_offset_dev = self._rng_dev()
+        if self.env_offset and hasattr(p, "env_offset"):
+            p.env_offset = self.env_offset
         return p
+
+    # index of this task's first environment in the whole (multi-GPU) job: with it, and one seed for all
+    # shards, the in-kernel draws of a shard are those of the unsharded run (distributed.env_shard gives it)
+    env_offset = 0
 
     def _rng_dev(self):
         """Address of the device-resident draw counter, or None.  isaacgym_amd.graph.GraphedStep installs the

@@ -44,7 +44,8 @@ class HandForcesMixin:
         ops.hand_random_forces(self.rb_forces, self.random_force_prob, self.reset_buf, self.object_rb_handles[0],
                                self.object_rb_masses[0], self.force_scale, rand=self.force_rand,
                                seed=(int(self.seed) * 0x9E3779B1 + 0x51ED) & 0xFFFFFFFFFFFFFFFF,
-                               rng_offset=self._force_draws, rng_offset_dev=self._force_rng_dev(), **self._force_consts)
+                               rng_offset=self._force_draws, rng_offset_dev=self._force_rng_dev(), env_offset=self.env_offset,
+                               **self._force_consts)
         self.sim.apply_rigid_body_forces(self.rb_forces)
 
     def _force_rng_dev(self):

@@ -299,7 +299,7 @@ class HumanoidAMP(HumanoidAMPBase):
         w["draws"] += 1
         ops.motion_sample_flagged(lib._tables, lib.sampling_cdf(), self.reset_buf, w["env_ids"], w["ids"], w["times"],
                                   random_time=self._state_init in (SI.Random, SI.Hybrid), seed=seed,
-                                  rng_offset=w["draws"], rng_offset_dev=self._rng_dev(), ref_init_prob=ref_prob,
+                                  rng_offset=w["draws"], rng_offset_dev=self._rng_dev(), ref_init_prob=ref_prob, env_offset=self.env_offset,
                                   default_env_ids=w["default_ids"])
         if ref_prob < 1.0:  # default pose: joints from the initial state, the root row stays (humanoid_amp_base.py:392-408)
             ops.humanoid_amp_reset(self._params(), self._buffers(), w["default_ids"],

@@ -89,6 +89,9 @@ class HumanoidImitate(VecTask):
         self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
+        # humanoid_imitate.py:581-582: reset_idx re-randomises, i.e. on steps where some env is reset
+        if self.randomize and bool(self.reset_buf.any()):
+            self.apply_randomizations(self.randomization_params)
         p, b = self._params(), self._buffers()
         if self._can_fuse_tail():  # clamped copy and time-out flags of VecTask.step in the same launch
             self._fuse_tail(p, b)

@@ -137,6 +137,8 @@ class LocomotionTask(VecTask):
             self.extras["true_objective"] = self._true_objective  # ant.py:332-337
 
     def reset_idx(self, env_ids):
+        if self.randomize:  # ant.py:341-342, humanoid.py:362-363: every reset_idx re-randomises first
+            self.apply_randomizations(self.randomization_params)
         env_ids = env_ids.to(self.device, torch.int64).contiguous()
         self._reset_kernel(self._params(), self._buffers(), env_ids)
         self.sim.notify_root_state(self.initial_root_states, env_ids)

@@ -74,9 +74,10 @@ float orc_philox_uniform(uint64_t seed, uint64_t offset, int64_t env, int j)
     return (float)(c[j & 3] >> 8) * (1.0f / 16777216.0f);
 }
 
-static float draw(const float *rand, int64_t e, int per_env, int j, uint64_t seed, uint64_t off)
+static float draw(const float *rand, int64_t e, int per_env, int j, uint64_t seed, uint64_t off, int64_t env_offset)
 {
-    return rand ? rand[e * per_env + j] : orc_philox_uniform(seed, off, e, j);
+    /* given draws are indexed by the local environment, the generator by its index in the whole job */
+    return rand ? rand[e * per_env + j] : orc_philox_uniform(seed, off, e + env_offset, j);
 }
 
 /* ------------------------------------------------------ math helpers --- */
@@ -238,10 +239,10 @@ int orc_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *
         int64_t prog = b->progress[e] + 1;
         int64_t rst = b->reset[e];
         if (rst != 0) {
-            float u0 = draw(b->rand, e, 4, 0, p->seed, p->rng_offset);
-            float u1 = draw(b->rand, e, 4, 1, p->seed, p->rng_offset);
-            float u2 = draw(b->rand, e, 4, 2, p->seed, p->rng_offset);
-            float u3 = draw(b->rand, e, 4, 3, p->seed, p->rng_offset);
+            float u0 = draw(b->rand, e, 4, 0, p->seed, p->rng_offset, p->env_offset);
+            float u1 = draw(b->rand, e, 4, 1, p->seed, p->rng_offset, p->env_offset);
+            float u2 = draw(b->rand, e, 4, 2, p->seed, p->rng_offset, p->env_offset);
+            float u3 = draw(b->rand, e, 4, 3, p->seed, p->rng_offset, p->env_offset);
             ds[0] = 0.9f * (u0 - 0.5f);
             ds[2] = 0.9f * (u1 - 0.5f);
             ds[1] = 0.5f * (u2 - 0.5f);
@@ -275,10 +276,10 @@ int orc_cartpole_reset(const igx_cartpole_params *p, const igx_cartpole_buffers 
     for (int64_t i = 0; i < m; ++i) {
         const int64_t e = env_ids[i];
         float *ds = b->dof_state + e * 4;
-        float u0 = draw(b->rand, e, 4, 0, p->seed, p->rng_offset);
-        float u1 = draw(b->rand, e, 4, 1, p->seed, p->rng_offset);
-        float u2 = draw(b->rand, e, 4, 2, p->seed, p->rng_offset);
-        float u3 = draw(b->rand, e, 4, 3, p->seed, p->rng_offset);
+        float u0 = draw(b->rand, e, 4, 0, p->seed, p->rng_offset, p->env_offset);
+        float u1 = draw(b->rand, e, 4, 1, p->seed, p->rng_offset, p->env_offset);
+        float u2 = draw(b->rand, e, 4, 2, p->seed, p->rng_offset, p->env_offset);
+        float u3 = draw(b->rand, e, 4, 3, p->seed, p->rng_offset, p->env_offset);
         ds[0] = 0.9f * (u0 - 0.5f);
         ds[2] = 0.9f * (u1 - 0.5f);
         ds[1] = 0.5f * (u2 - 0.5f);
@@ -297,8 +298,8 @@ int orc_loco_reset(const igx_loco_params *p, const igx_loco_buffers *b, const in
         const int64_t e = env_ids[i];
         float *ds = b->dof_state + e * D * 2;
         for (int j = 0; j < D; ++j) {
-            float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset);
-            float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset);
+            float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset, p->env_offset);
+            float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset, p->env_offset);
             float pos = 0.4f * up + (-0.2f);
             float vel = 0.2f * uv + (-0.1f);
             float t = b->initial_dof_pos[e * D + j] + pos;
@@ -345,8 +346,8 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
 
         if (rst != 0) { /* reset_idx */
             for (int j = 0; j < D; ++j) {
-                float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset);
-                float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset);
+                float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset, p->env_offset);
+                float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset, p->env_offset);
                 /* torch_rand_float: (upper - lower) * rand + lower */
                 float pos = 0.4f * up + (-0.2f);
                 float vel = 0.2f * uv + (-0.1f);
@@ -982,7 +983,7 @@ int orc_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffe
         float r[IGX_ALLEGRO_RAND_PER_ENV];
         if (rst || rg)
             for (int k = 0; k < R; ++k) /* torch_rand_float(-1, 1): (upper - lower) * u + lower */
-                r[k] = 2.0f * draw(b->rand, e, R, k, p->seed, p->rng_offset) + (-1.0f);
+                r[k] = 2.0f * draw(b->rand, e, R, k, p->seed, p->rng_offset, p->env_offset) + (-1.0f);
         if (rg) allegro_reset_target_pose(p, b, e, r[0], r[1]);
         if (rst) {
             const float *rf = r + 4; /* the 37 floats of reset_idx */
@@ -1190,7 +1191,7 @@ int orc_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers 
         const int rst = b->reset[e] != 0, rg = b->reset_goal[e] != 0;
         float r[IGX_SHADOW_RAND_PER_ENV];
         if (rst || rg)
-            for (int k = 0; k < R; ++k) r[k] = 2.0f * draw(b->rand, e, R, k, p->seed, p->rng_offset) + (-1.0f);
+            for (int k = 0; k < R; ++k) r[k] = 2.0f * draw(b->rand, e, R, k, p->seed, p->rng_offset, p->env_offset) + (-1.0f);
         if (rg) shadow_reset_target_pose(p, b, e, r[0], r[1]);
         if (rst) {
             const float *rf = r + 4;
@@ -1570,13 +1571,13 @@ int orc_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampl
     for (int64_t e = 0; e < n; ++e) {
         int64_t id = -1, env = -1, denv = -1;
         double time = 0.0;
-        if (reset[e] != 0 && !(orc_philox_uniform(s->seed, s->rng_offset, e, 2) < s->ref_init_prob)) {
+        if (reset[e] != 0 && !(orc_philox_uniform(s->seed, s->rng_offset, e + s->env_offset, 2) < s->ref_init_prob)) {
             denv = e; /* tasks/humanoid_amp.py:248-261: this one takes the default pose */
         } else if (reset[e] != 0) {
-            double pick = (double)orc_philox_uniform(s->seed, s->rng_offset, e, 0);
+            double pick = (double)orc_philox_uniform(s->seed, s->rng_offset, e + s->env_offset, 0);
             id = 0;
             while (id < t->num_motions - 1 && !(pick < s->cdf[id])) ++id;
-            time = s->random_time ? (double)orc_philox_uniform(s->seed, s->rng_offset, e, 1) * t->motion_length[id] : 0.0;
+            time = s->random_time ? (double)orc_philox_uniform(s->seed, s->rng_offset, e + s->env_offset, 1) * t->motion_length[id] : 0.0;
             env = e;
         }
         env_ids[e] = env;
@@ -1794,8 +1795,8 @@ int orc_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_hu
         if (b->randomize) b->randomize[e] += 1;
         if (rst != 0) {
             for (int j = 0; j < D; ++j) {
-                float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset);
-                float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset);
+                float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset, p->env_offset);
+                float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset, p->env_offset);
                 float t = b->initial_dof_pos[e * D + j] + (0.4f * up + (-0.2f));
                 t = fminf(t, p->dof_limits_upper[j]);
                 t = fmaxf(t, p->dof_limits_lower[j]);
@@ -1860,10 +1861,10 @@ int orc_hand_random_forces(const igx_hand_forces *f, int64_t n)
             const float *r = f->rand + e * IGX_HAND_FORCE_RAND_PER_ENV;
             u_prob = r[0]; u_sel = r[1]; z[0] = r[2]; z[1] = r[3]; z[2] = r[4];
         } else {  /* the library's own stream: uniforms 0..5 of the environment, Box-Muller on (2,3) and (4,5) */
-            const float u2 = orc_philox_uniform(f->seed, f->rng_offset, e, 2), u3 = orc_philox_uniform(f->seed, f->rng_offset, e, 3);
-            const float v0 = orc_philox_uniform(f->seed, f->rng_offset, e, 4), v1 = orc_philox_uniform(f->seed, f->rng_offset, e, 5);
-            u_prob = orc_philox_uniform(f->seed, f->rng_offset, e, 0);
-            u_sel = orc_philox_uniform(f->seed, f->rng_offset, e, 1);
+            const float u2 = orc_philox_uniform(f->seed, f->rng_offset, e + f->env_offset, 2), u3 = orc_philox_uniform(f->seed, f->rng_offset, e + f->env_offset, 3);
+            const float v0 = orc_philox_uniform(f->seed, f->rng_offset, e + f->env_offset, 4), v1 = orc_philox_uniform(f->seed, f->rng_offset, e + f->env_offset, 5);
+            u_prob = orc_philox_uniform(f->seed, f->rng_offset, e + f->env_offset, 0);
+            u_sel = orc_philox_uniform(f->seed, f->rng_offset, e + f->env_offset, 1);
             const float r0 = sqrtf(-2.0f * logf(1.0f - u2)), a0 = 6.2831855f * u3;
             const float r1 = sqrtf(-2.0f * logf(1.0f - v0)), a1 = 6.2831855f * v1;
             z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1);

@@ -381,14 +381,14 @@ def ant_imitate_step(params, bufs, im, arrays, n):
 
 
 def hand_random_forces(rb_forces, random_force_prob, reset, object_rb_handle, object_rb_mass, force_scale, decay,
-                       log_prob_lo, log_prob_hi, rand=None, seed=0, rng_offset=0):
+                       log_prob_lo, log_prob_hi, rand=None, seed=0, rng_offset=0, env_offset=0):
     """CPU restatement of igx_hand_random_forces (tasks/allegro_hand.py:532, :558-559, :617-625)."""
     n, nb = rb_forces.shape[0], rb_forces.shape[1]
     s = _abi.HandForces(rb_forces=_np_ptr(rb_forces), random_force_prob=_np_ptr(random_force_prob), reset=_np_ptr(reset),
                         rand=_np_ptr(rand) if rand is not None else None, num_bodies=int(nb),
                         object_rb_handle=int(object_rb_handle), object_rb_mass=float(object_rb_mass),
                         force_scale=float(force_scale), decay=float(decay), log_prob_lo=float(log_prob_lo),
-                        log_prob_hi=float(log_prob_hi), seed=int(seed), rng_offset=int(rng_offset))
+                        log_prob_hi=float(log_prob_hi), seed=int(seed), rng_offset=int(rng_offset), env_offset=int(env_offset))
     assert lib().orc_hand_random_forces(C.byref(s), C.c_int64(n)) == 0
 
 

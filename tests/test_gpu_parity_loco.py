@@ -271,3 +271,33 @@ def test_device_resident_draw_counter_adds_to_rng_offset():
     other["reset"][::2] = 1
     ops.ant_step(synthetic.loco_params(spec, seed=99, rng_offset=5), other, n)
     assert not torch.equal(other["dof_state"], t["dof_state"])
+
+
+@pytest.mark.parametrize("spec,step", [(synthetic.ANT, ops.ant_step), (synthetic.HUMANOID, ops.humanoid_step)])
+def test_two_shards_draw_what_one_gpu_draws(spec, step):
+    """In-kernel resets (rand == NULL): two environment shards that share the seed and pass their env_offset
+    equal the unsharded call bit for bit."""
+    from isaacgym_amd import distributed
+    n = 10007
+    full = synthetic.loco_state(spec, n, 3, DEV)
+    full["reset"].fill_(0)
+    full["reset"][::3] = 1
+    shards = []
+    for r in range(2):
+        s, c = distributed.env_shard(n, r, 2)
+        shards.append((s, c, {k: (v[s:s + c].clone() if v is not None else None) for k, v in full.items()}))
+    p = synthetic.loco_params(spec, seed=77, rng_offset=5)
+    step(p, full, n)
+    for s, c, sh in shards:
+        ps = synthetic.loco_params(spec, seed=77, rng_offset=5)
+        ps.env_offset = s
+        step(ps, sh, c)
+        for k in ("dof_state", "obs", "rew", "reset", "progress", "potentials"):
+            assert torch.equal(sh[k].view(torch.uint8), full[k][s:s + c].view(torch.uint8)), k
+    s, c, sh = shards[1]
+    again = synthetic.loco_state(spec, n, 3, DEV)
+    again["reset"].fill_(0)
+    again["reset"][::3] = 1
+    wrong = {k: (v[s:s + c].clone() if v is not None else None) for k, v in again.items()}
+    step(synthetic.loco_params(spec, seed=77, rng_offset=5), wrong, c)  # env_offset forgotten: other draws
+    assert not torch.equal(wrong["dof_state"], full["dof_state"][s:s + c])

@@ -526,3 +526,28 @@ def test_force_scale_zero_launches_nothing():
     task = tasks.make("AllegroHand", 256, DEV, seed=4)
     task.step(torch.zeros(256, 16, device=DEV))
     assert not (task.rb_forces != 0).any() and "rigid_body_force" not in task.sim.tensors
+
+
+@pytest.mark.parametrize("name", ["Ant", "AntImitate"])
+def test_resets_re_randomise_like_the_reference(name):
+    """ant.py:341-342 / ant_imitate.py:370-371: reset_idx calls apply_randomizations whenever task.randomize is
+    set - also when it is reached through reset_done(), and in AntImitate's own post_physics_step."""
+    n = 512
+    cfg = C.task_config(name, n)
+    cfg["task"]["randomize"] = True
+    kw = {}
+    if name == "AntImitate":
+        lo, hi = (np.asarray(v, np.float64) for v in synthetic.loco_limits(8))
+        kw["motion"] = lo + (hi - lo) * np.random.default_rng(0).random((64, 8))
+    task = tasks.isaacgym_task_map[name](cfg, DEV, DEV, 0, True, False, False, sim=SyntheticSim(name, n, DEV, seed=2), seed=2, **kw)
+    calls = []
+    real = task.apply_randomizations
+    task.apply_randomizations = lambda params: (calls.append(1), real(params))[1]
+    task.reset_done()                      # reset_buf starts at ones -> reset_idx(all)
+    assert len(calls) == 1
+    task.reset_buf.zero_()
+    task.step(torch.zeros(n, 8, device=DEV))
+    quiet = len(calls)                     # nothing flagged at the start of that step: no call from post_physics_step
+    task.reset_buf[5] = 1
+    task.step(torch.zeros(n, 8, device=DEV))
+    assert len(calls) == quiet + 1

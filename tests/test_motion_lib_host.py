@@ -1,6 +1,7 @@
 """Host side of the product MotionLib (no GPU): load-time tables and numpy-RNG
 sampling against what the reference MotionLib produced (tests/golden/motion.npz)."""
 import numpy as np
+import torch
 import pytest
 
 from isaacgym_amd.tasks.amp.utils_amp.motion_lib import MotionLib, load_motion_file
@@ -51,10 +52,55 @@ def test_no_silent_cpu_path(lib):
         ml.get_motion_state(g["ids"][:4], g["times"][:4])
 
 
-def test_pickled_motion_needs_opt_in(tmp_path):
+def _poselib_dict(F=5, J=15):
+    rng = np.random.default_rng(0)
+    from collections import OrderedDict
+    arr = lambda a: OrderedDict(arr=a, context=dict(dtype=str(a.dtype)))
+    q = rng.standard_normal((F, J, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    tree = OrderedDict(node_names=["b%d" % i for i in range(J)],
+                       parent_indices=arr(np.array([-1, 0, 1, 1, 3, 4, 1, 6, 7, 0, 9, 10, 0, 12, 13], np.int64)),
+                       local_translation=arr(rng.standard_normal((J, 3)).astype(np.float32)))
+    return OrderedDict(rotation=arr(q), root_translation=arr(rng.standard_normal((F, 3)).astype(np.float32)),
+                       global_velocity=arr(rng.standard_normal((F, J, 3)).astype(np.float32)),
+                       global_angular_velocity=arr(rng.standard_normal((F, J, 3)).astype(np.float32)),
+                       skeleton_tree=tree, is_local=True, fps=np.float64(30.0), __name__="SkeletonMotion")
+
+
+def test_poselib_npy_is_read_without_numpy_pickle_loading(tmp_path):
+    """A .npy written the way poselib writes motions (np.save of a dict) loads through the restricted
+    unpickler and equals its .npz conversion."""
+    from isaacgym_amd.tasks.amp.utils_amp.motion_lib import convert_npy, read_poselib_npy
     p = tmp_path / "m.npy"
+    d = _poselib_dict()
+    np.save(p, d)
+    got = read_poselib_npy(str(p))
+    assert np.array_equal(got["rotation"]["arr"], d["rotation"]["arr"]) and got["fps"] == 30.0
+    m = load_motion_file(str(p))
+    convert_npy(str(p), str(tmp_path / "m.npz"))
+    m2 = load_motion_file(str(tmp_path / "m.npz"))
+    assert torch.equal(m.rotation, m2.rotation) and m.parent_indices == m2.parent_indices and m.fps == m2.fps
+
+
+class _Evil:
+    def __reduce__(self):
+        import os
+        return (os.system, ("echo should-never-run > /dev/null",))
+
+
+def test_pickle_naming_any_other_global_is_rejected(tmp_path):
+    import pickle
+    from isaacgym_amd.tasks.amp.utils_amp.motion_lib import read_poselib_npy
+    for payload in ({"rotation": _Evil()}, {"x": np.float32}, {"f": print}):
+        p = tmp_path / "evil.npy"
+        np.save(p, payload, allow_pickle=True)
+        with pytest.raises(pickle.UnpicklingError, match="refusing"):
+            read_poselib_npy(str(p))
+        with pytest.raises(pickle.UnpicklingError):
+            load_motion_file(str(p))
+    p = tmp_path / "plain.npy"
     np.save(p, np.zeros(3))
-    with pytest.raises(ValueError, match="allow_pickle"):
+    with pytest.raises(ValueError, match="not a poselib motion"):
         load_motion_file(str(p))
     with pytest.raises(ValueError):
         MotionLib(str(p), 27, [5, 8, 11, 14], "cpu")
