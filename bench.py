@@ -15,7 +15,8 @@ Rank 0 prints ONE JSON line.  `value` is whole-job env-steps/s with all inputs
 resident in HBM.  `roofline` prices the dominant (only) kernel against the HBM
 peak using 556 algorithmic bytes per env-step; `cpu_baseline` times the CPU
 checker (oracle/, a scalar C restatement of the reference's torch.jit path,
-OpenMP over envs) on this box's host cores for a bounded sample.
+OpenMP over envs) and the torch-op restatement of the reference's CPU pipeline
+(oracle/torch_ref.py) on this box's host cores for a bounded sample each.
 """
 import argparse
 import json
@@ -55,31 +56,63 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(spec, n, task):
-    """Time the CPU checker on a bounded sample of the same workload."""
-    import numpy as np
+def _time_loop(fn, budget_s, max_steps):
+    fn(0)  # warm-up (page faults, thread pool start)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        fn(steps + 1)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or steps >= max_steps:
+            return steps, dt
+
+
+def cpu_baseline(spec, n, task, budget_s=10.0):
+    """The same workload on this box's host cores, on a bounded sample (about `budget_s` seconds each):
+    `torch_ref` = the step as the reference runs it on a CPU pipeline - unfused torch tensor ops, one ATen
+    kernel per arithmetic step (oracle/torch_ref.py, bit-checked against the recording of the reference's
+    Ant class) - and `port` = the scalar C restatement with OpenMP over environments (oracle/igx_oracle.c).
+    Both use the threads this process was given (OMP_NUM_THREADS / torch's default); host_cpus is what the
+    machine has."""
     import torch
     from isaacgym_amd import synthetic
     from oracle import oracle
 
-    cores = min(16, os.cpu_count() or 1)
-    cores = oracle.set_num_threads(cores)
+    host_cpus = os.cpu_count() or 1
+    env_threads = os.environ.get("OMP_NUM_THREADS")
+    threads = int(env_threads) if env_threads and env_threads.isdigit() else host_cpus
+    out = {"unit": "env-steps/s", "kind": "port", "host_cpus": host_cpus}
+
+    cores = oracle.set_num_threads(threads)
     p = synthetic.loco_params(spec, seed=1, rng_offset=0)
     t = synthetic.loco_state(spec, n, 0, "cpu")
     bufs = {k: v.numpy() for k, v in t.items()}
     step = oracle.ant_step if task == "ant" else oracle.humanoid_step
-    step(p, bufs, n)  # warm-up (page faults)
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        p.rng_offset = steps + 1
+
+    def port_step(i):
+        p.rng_offset = i
         step(p, bufs, n)
-        steps += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0 or steps >= 4096:
-            break
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of %d envs (%s), %.1f s wall" % (steps, n, task, dt)}
+    steps, dt = _time_loop(port_step, budget_s, 4096)
+    out["port"] = {"value": n * steps / dt, "cores": cores,
+                   "sample": "%d steps of %d envs (%s), %.1f s wall, C restatement + OpenMP" % (steps, n, task, dt)}
+
+    if task == "ant":
+        from oracle import torch_ref
+        tthreads = torch_ref.configure_like_the_task(threads)
+        tb = synthetic.loco_state(spec, n, 0, "cpu")
+        tb["true_objective"] = torch.zeros(n)
+        ref = torch_ref.AntStepRef(synthetic.loco_params(spec, seed=1), tb, n)
+        with torch.no_grad():
+            steps, dt = _time_loop(lambda i: ref.step(), budget_s, 4096)
+        out["torch_ref"] = {"value": n * steps / dt, "cores": tthreads,
+                            "sample": "%d steps of %d envs (%s), %.1f s wall, unfused torch CPU ops (torch %s)"
+                                      % (steps, n, task, dt, torch.__version__)}
+        head = out["torch_ref"]
+    else:
+        head = out["port"]
+    out.update(value=head["value"], cores=head["cores"], sample=head["sample"])
+    return out
 
 
 def load_traffic():

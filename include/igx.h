@@ -216,7 +216,7 @@ int igx_ant_imitate_finish(const igx_loco_params *p, const igx_loco_buffers *b, 
 int igx_quantile_begin(void *workspace, double q, int64_t n_total, igx_stream_t stream);
 int igx_quantile_histogram(const double *x, int64_t n, void *workspace, int32_t pass, igx_stream_t stream);
 int igx_quantile_finish(void *workspace, double *out, igx_stream_t stream);
-/* torch.quantile(x, q) (linear interpolation) of n doubles -> *out (device); x must hold no NaN */
+/* torch.quantile(x, q) (linear interpolation) of n doubles -> *out (device); NaN if any element is NaN, as torch */
 int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
@@ -760,6 +760,8 @@ int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t row_width, c
                         int32_t num_cols, int32_t ring_slots, int64_t max_steps);
 /* Capture src [n_rows,row_width] (device) as the next step; asynchronous.
  * IGX_E_SIZE once max_steps captures have been taken. */
+/* (capture and sync order the copy only against the stream of the LAST capture: a producer that changes
+ * streams must order them itself; the recorder's device must be the current device of every call) */
 int igx_recorder_capture(igx_recorder *r, const float *src, igx_stream_t producer_stream);
 /* Block the host until every capture so far has landed in host memory (a partly filled batch is
  * copied now, ordered behind the stream of the last capture). */

@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const double *__rest
     const unsigned long long p0 = s_st.prefix[0], p1 = s_st.prefix[1];
     const bool same = p0 == p1;
     auto count = [&](double v) {
+        // NaN: torch.quantile answers NaN as soon as one element is NaN.  Pass 0 uses 512 of its 2048 bins;
+        // the last bin of its first histogram counts the NaNs (and is all-reduced with it in sharded runs).
+        if (pass == 0 && v != v) atomicAdd(&s_hist[0][QBINS - 1], 1u);
         const unsigned long long k = key_of(v);
         const unsigned long long hi = pass == 0 ? 0ull : (k >> (shift + bits));
         const unsigned d = (unsigned)((k >> shift) & ((1u << bits) - 1u));
@@ -178,7 +181,8 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(QuantileState *sta
         const double a = value_of(s_st.prefix[0]), b = value_of(s_st.prefix[1]), w = s_st.weight;
         // at::native lerp as torch's CPU kernel evaluates it: one fused multiply-add onto the nearer end
         const double diff = b - a;
-        const double r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+        double r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+        if (hist_of(states, 0)[QBINS - 1] != 0) r = __longlong_as_double(0x7ff8000000000000ll);  // some element was NaN
         s_st.result = r;
         states[QPASSES] = s_st;
         states[0].result = r;

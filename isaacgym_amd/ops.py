@@ -418,7 +418,8 @@ def ant_imitate_finish(params, tensors, im, n_envs):
 
 
 def quantile_f64(x, q, workspace=None):
-    """torch.quantile(x, q) of a 1-D fp64 device tensor (no NaN): exact radix select; returns a 0-dim tensor."""
+    """torch.quantile(x, q) of a 1-D fp64 device tensor: exact radix select (NaN if any element is NaN);
+    returns a 0-dim tensor."""
     dev = x.device
     if workspace is None:
         workspace = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=dev)

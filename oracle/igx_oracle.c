@@ -1648,6 +1648,8 @@ static int cmp_double(const void *a, const void *b)
 /* torch.quantile(x, q), 'linear': sort, ranks = q * (n - 1), lerp(below, above, frac) */
 double orc_quantile_f64(const double *x, int64_t n, double q)
 {
+    for (int64_t i = 0; i < n; ++i)
+        if (x[i] != x[i]) return NAN;  /* torch.quantile propagates NaN */
     double *s = (double *)malloc(sizeof(double) * (size_t)n);
     memcpy(s, x, sizeof(double) * (size_t)n);
     qsort(s, (size_t)n, sizeof(double), cmp_double);
@@ -1725,6 +1727,7 @@ int orc_quantile_histogram(const double *x, int64_t n, void *ws, int32_t pass)
     const int shift = q_shift(pass), bits = q_bits(pass);
     const int same = cur->prefix[0] == cur->prefix[1];
     for (int64_t i = 0; i < n; ++i) {
+        if (pass == 0 && x[i] != x[i]) hist[2047] += 1;  /* spare bin of pass 0: the NaN count */
         uint64_t k = q_key(x[i]);
         uint64_t hi = pass == 0 ? 0 : (k >> (shift + bits));
         unsigned d = (unsigned)((k >> shift) & ((1u << bits) - 1u));
@@ -1741,6 +1744,7 @@ int orc_quantile_finish(void *ws, double *out)
     q_advance(&st[last], q_hist(ws, last), last, &st[last + 1]);
     double a = q_value(st[last + 1].prefix[0]), b = q_value(st[last + 1].prefix[1]), w = st[last + 1].weight;
     double diff = b - a, r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+    if (q_hist(ws, 0)[2047] != 0) r = NAN;
     st[last + 1].result = r;
     st[0].result = r;
     if (out) *out = r;
@@ -1755,7 +1759,8 @@ int orc_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b,
 /* tasks/ant_imitate.py:523-555 given the global threshold */
 int orc_ant_imitate_finish(const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n, double quantile_value)
 {
-    double thr = im->distance_floor > quantile_value ? im->distance_floor : quantile_value;
+    /* Python's max(1.8, quantile): the second argument only if it compares greater (a NaN quantile leaves 1.8) */
+    double thr = quantile_value > im->distance_floor ? quantile_value : im->distance_floor;
     for (int64_t e = 0; e < n; ++e) {
         int64_t idx = im->target_pose_idx[e];
         if (im->pose_diff[e] > thr) {

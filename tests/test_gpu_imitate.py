@@ -136,3 +136,15 @@ def test_ant_imitate_vs_oracle(n):
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew")
         for k in ("dof_state", "potentials", "prev_potentials"):
             assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k
+
+
+@pytest.mark.parametrize("n", [5, 4097, 300001])
+def test_quantile_with_a_nan_is_nan_like_torch(n):
+    g = torch.Generator().manual_seed(n)
+    for bits in (0x7ff8000000000000, 0xfff8000000000001 - (1 << 64)):  # a positive and a negative NaN
+        x = torch.randn(n, generator=g, dtype=torch.float64)
+        x[n // 2] = torch.tensor([bits], dtype=torch.int64).view(torch.float64)[0]
+        assert torch.isnan(torch.quantile(x, 0.99))
+        assert torch.isnan(ops.quantile_f64(x.to(DEV), 0.99))
+    x = torch.randn(n, generator=g, dtype=torch.float64)
+    assert float(ops.quantile_f64(x.to(DEV), 0.99)) == float(torch.quantile(x, 0.99))  # the same workspace logic without NaN

@@ -58,3 +58,15 @@ def test_quantile_random_ranks_and_weights_equal_torch():
         x = rng.standard_normal(n) ** 3
         q = float(rng.random())
         assert oracle.quantile_f64(x, q) == float(torch.quantile(torch.from_numpy(x), q)), (n, q)
+
+
+def test_quantile_restatement_propagates_nan_like_torch():
+    rng = np.random.default_rng(3)
+    for nan in (np.nan, -np.nan):
+        x = rng.standard_normal(1001)
+        x[17] = nan
+        assert np.isnan(float(torch.quantile(torch.from_numpy(x), 0.99)))
+        assert np.isnan(oracle.quantile_f64(x, 0.99))
+    # and the reference's max(1.8, quantile) then keeps 1.8 (Python's max returns its first argument unless the
+    # second compares greater), so environments further than 1.8 are still reset
+    assert max(1.8, torch.tensor(float("nan"))) == 1.8
