@@ -353,6 +353,8 @@ typedef struct igx_allegro_buffers {
     float *obs_clamped;               /* [N,num_obs] clamp(obs, -clip_obs, clip_obs) */
     float *states_clamped;            /* [N,88] clamp(states, ...); needs states */
     uint8_t *time_outs;               /* [N] bool (progress >= episodeLength - 1) & (reset != 0) after the step */
+    void *shard_record;               /* igx_*_post_physics_shard only, optional: the call's 16-byte record is ALSO written here
+                                         (a slot of a caller-side queue of records, one per step) */
 } igx_allegro_buffers;
 
 int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
@@ -385,6 +387,13 @@ int igx_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegr
                                    igx_stream_t stream);
 int igx_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
                                 int32_t num_shards, igx_stream_t stream);
+/* The same for num_steps queued steps at once, so that the all-gather can leave the step's critical path:
+ * every shard call leaves its record in slot t of a queue (b->shard_record), the queues of all shards are
+ * gathered once per horizon (on a side stream), and consecutive_successes is advanced step by step, in step
+ * order - bit for bit what num_steps calls of igx_allegro_finalize_shards give.
+ * records: [num_shards][num_steps] 16-byte records (shard-major, as an all-gather of the queues lays them out). */
+int igx_allegro_finalize_shards_queued(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
+                                       int32_t num_shards, int32_t num_steps, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * ShadowHand in-hand reorientation (tasks/shadow_hand.py): the same task family as
@@ -462,6 +471,8 @@ typedef struct igx_shadow_buffers {
     float *obs_clamped;               /* as in igx_allegro_buffers */
     float *states_clamped;            /* [N,211] */
     uint8_t *time_outs;
+    void *shard_record;               /* igx_*_post_physics_shard only, optional: the call's 16-byte record is ALSO written here
+                                         (a slot of a caller-side queue of records, one per step) */
 } igx_shadow_buffers;
 
 int igx_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n_envs, igx_stream_t stream);
@@ -471,6 +482,8 @@ int igx_shadow_post_physics_shard(const igx_shadow_params *p, const igx_shadow_b
                                   igx_stream_t stream);
 int igx_shadow_finalize_shards(const igx_shadow_params *p, const igx_shadow_buffers *b, const void *records,
                                int32_t num_shards, igx_stream_t stream);
+int igx_shadow_finalize_shards_queued(const igx_shadow_params *p, const igx_shadow_buffers *b, const void *records,
+                                      int32_t num_shards, int32_t num_steps, igx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Random disturbance forces on the manipulated object of AllegroHand / ShadowHand: everything

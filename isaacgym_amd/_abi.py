@@ -111,7 +111,7 @@ class AllegroBuffers(_Struct):
                 ("obs", ptr), ("states", ptr), ("rew", ptr),
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
                 ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr),
-                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr)]
+                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr), ("shard_record", ptr)]
 
 IGX_SHADOW_DOF, IGX_SHADOW_ACTIONS, IGX_SHADOW_FINGERTIPS, IGX_SHADOW_RAND_PER_ENV = 24, 20, 5, 61
 IGX_SHADOW_OBS = {"openai": 0, "full_no_vel": 1, "full": 2, "full_state": 3}
@@ -145,7 +145,7 @@ class ShadowBuffers(_Struct):
                 ("obs", ptr), ("states", ptr), ("rew", ptr),
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
                 ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr),
-                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr)]
+                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr), ("shard_record", ptr)]
 
 
 IGX_HAND_FORCE_RAND_PER_ENV = 5
@@ -334,7 +334,7 @@ def _hand_widths(dof, actions, rand, nobs, nstates, extra):
              actions=_env(actions), prev_targets=_env(dof), cur_targets=_env(dof), rand=_env(rand), obs=_env(nobs),
              states=_env(nstates), rew=_ONE, reset=_ONE, reset_goal=_ONE, progress=_ONE, randomize=_ONE,
              successes=_ONE, consecutive_successes=("fixed", 1), workspace=("bytes", IGX_ALLEGRO_WORKSPACE_BYTES),
-             obs_clamped=_env(nobs), states_clamped=_env(nstates), time_outs=_ONE)
+             obs_clamped=_env(nobs), states_clamped=_env(nstates), time_outs=_ONE, shard_record=("bytes", lambda n: 16))
     w.update(extra)
     return w
 

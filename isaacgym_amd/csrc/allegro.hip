@@ -462,6 +462,20 @@ extern "C" int igx_allegro_finalize_shards(const igx_allegro_params *p, const ig
         return fail(IGX_E_NULL, "igx_allegro_finalize_shards: records / consecutive_successes is NULL");
     if (!aligned16(records)) return fail(IGX_E_ALIGN, "igx_allegro_finalize_shards: records must be 16-byte aligned");
     hipLaunchKernelGGL((hand_finalize_kernel<igx_allegro_params, igx_allegro_buffers>), dim3(1), dim3(1), 0,
-                       static_cast<hipStream_t>(stream), *p, *b, static_cast<const HandRecord *>(records), (int)num_shards);
+                       static_cast<hipStream_t>(stream), *p, *b, static_cast<const HandRecord *>(records), (int)num_shards, 1);
     return launch_status("igx_allegro_finalize_shards");
+}
+
+extern "C" int igx_allegro_finalize_shards_queued(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
+                                           int32_t num_shards, int32_t num_steps, igx_stream_t stream)
+{
+    if (!p || !b) return fail(IGX_E_NULL, "igx_allegro_finalize_shards_queued: params/buffers struct is NULL");
+    if (num_shards < 1 || num_shards > 65536) return fail(IGX_E_SIZE, "igx_allegro_finalize_shards_queued: num_shards %d", num_shards);
+    if (num_steps < 1 || num_steps > 65536) return fail(IGX_E_SIZE, "igx_allegro_finalize_shards_queued: num_steps %d", num_steps);
+    if (!records || !b->consecutive_successes)
+        return fail(IGX_E_NULL, "igx_allegro_finalize_shards_queued: records / consecutive_successes is NULL");
+    if (!aligned16(records)) return fail(IGX_E_ALIGN, "igx_allegro_finalize_shards_queued: records must be 16-byte aligned");
+    hipLaunchKernelGGL((hand_finalize_kernel<igx_allegro_params, igx_allegro_buffers>), dim3(1), dim3(1), 0,
+                       static_cast<hipStream_t>(stream), *p, *b, static_cast<const HandRecord *>(records), (int)num_shards, (int)num_steps);
+    return launch_status("igx_allegro_finalize_shards_queued");
 }

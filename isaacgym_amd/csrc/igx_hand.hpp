@@ -190,22 +190,32 @@ __global__ __launch_bounds__(1024) void hand_reduce_kernel(const P p, const B b,
     if (t == 0) {
         ws[WS_RESULT].num_resets = s_cnt[0];
         ws[WS_RESULT].finished = s_fin[0];
-        if (FINALIZE) update_consecutive_successes(p, b, s_cnt[0], s_fin[0]);
+        if (FINALIZE) {
+            update_consecutive_successes(p, b, s_cnt[0], s_fin[0]);
+        } else if (b.shard_record) {  // the caller's queue of per-step records
+            HandRecord *q = reinterpret_cast<HandRecord *>(b.shard_record);
+            q->num_resets = s_cnt[0];
+            q->finished = s_fin[0];
+        }
     }
 }
 
 // consecutive_successes from the records of all shards, added in index order, so every
 // rank of a sharded run computes the same bits
 template <class P, class B>
-__global__ void hand_finalize_kernel(const P p, const B b, const HandRecord *__restrict__ records, int num_records)
+__global__ void hand_finalize_kernel(const P p, const B b, const HandRecord *__restrict__ records, int num_records,
+                                     int num_steps)
 {
-    unsigned long long num_resets = 0;
-    double finished = 0.0;
-    for (int i = 0; i < num_records; ++i) {
-        num_resets += records[i].num_resets;
-        finished += records[i].finished;
+    // records[shard * num_steps + step]; steps strictly in order (the moving average is not associative)
+    for (int t = 0; t < num_steps; ++t) {
+        unsigned long long num_resets = 0;
+        double finished = 0.0;
+        for (int i = 0; i < num_records; ++i) {
+            num_resets += records[(int64_t)i * num_steps + t].num_resets;
+            finished += records[(int64_t)i * num_steps + t].finished;
+        }
+        update_consecutive_successes(p, b, num_resets, finished);
     }
-    update_consecutive_successes(p, b, num_resets, finished);
 }
 
 // ---- one 13-float actor row per environment of the tile, addressed by an index tensor.

@@ -105,3 +105,84 @@ def max_over_ranks(value, device, group=None):
     if world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+class ShardRecordQueue:
+    """Keeps a per-step exchange of small records off the step's critical path.
+
+    A sharded task whose step ends in a tiny all-gather (AllegroHand / ShadowHand: the 16-byte
+    {num_resets, sum} record behind `consecutive_successes`) would otherwise pay one collective latency
+    per step on its own stream.  Here every step writes its record into a slot of a device-side queue
+    (`slot()`, handed to the kernel as `shard_record`); once per `interval` steps `flush()` gathers the
+    whole queue of every rank with ONE collective on a side stream and calls `apply(records, num_steps)`
+    there, which advances the running value step by step in step order - the same arithmetic in the same
+    order as the per-step exchange, so the bits are those of the per-step path.
+
+    The running value lives in `pending` (owned by the side stream); `visible` - what the task exposes -
+    is refreshed from it at the next flush, after the task stream has waited for the previous horizon's
+    event.  So a reader on the task stream never races with the side stream and sees, at any step, the
+    value as of the end of the last horizon but one.  `drain()` brings `visible` fully up to date
+    (synchronises the task stream with the side stream)."""
+
+    def __init__(self, visible, interval, group=None, record_words=2):
+        self.visible = visible
+        self.pending = visible.clone()
+        self.interval = max(1, int(interval))
+        self.group = group
+        dev = visible.device
+        self._cuda = dev.type == "cuda"
+        self._rings = [torch.zeros(self.interval, record_words, dtype=torch.int64, device=dev) for _ in range(2)]
+        # persistent views: the kernels' argument cache recognises a slot by the tensor object
+        self._slots = [[r[i] for i in range(self.interval)] for r in self._rings]
+        self._cur, self._count = 0, 0
+        self._side = torch.cuda.Stream(device=dev) if self._cuda else None
+        self._done = None          # event: the side stream finished the last flushed horizon
+        self._dirty = False        # pending holds something visible has not seen
+        self.flushes = 0
+
+    def slot(self):
+        """Where this step's record goes (a 16-byte tensor view)."""
+        return self._slots[self._cur][self._count]
+
+    def push(self):
+        """The step that used slot() has been enqueued; True when the queue is full and must be flushed."""
+        self._count += 1
+        return self._count >= self.interval
+
+    def _refresh_visible(self):
+        if self._done is not None:
+            torch.cuda.current_stream(self.visible.device).wait_event(self._done)
+            self._done = None
+        if self._dirty:
+            self.visible.copy_(self.pending)
+            self._dirty = False
+
+    def flush(self, apply):
+        """Gather the queued records of all ranks and run apply(records [world, steps * words], steps)."""
+        k = self._count
+        if k == 0:
+            return
+        ring = self._rings[self._cur][:k]
+        self._cur ^= 1
+        self._count = 0
+        self._refresh_visible()  # the previous horizon's result becomes visible; its ring is free again
+        if self._cuda:
+            dev = self.visible.device
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                records = gather_records(ring.reshape(-1), self.group)
+                apply(records.contiguous(), k)
+                self._done = torch.cuda.Event()
+                self._done.record(self._side)
+        else:
+            records = gather_records(ring.reshape(-1), self.group)
+            apply(records.contiguous(), k)
+        self._dirty = True
+        self.flushes += 1
+
+    def drain(self, apply):
+        """Flush what is queued and make `visible` current."""
+        self.flush(apply)
+        self._refresh_visible()

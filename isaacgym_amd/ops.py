@@ -10,16 +10,16 @@ import torch
 from . import _abi, _lib
 
 
-def cartpole_step(params, tensors, n_envs):
-    _lib.call_step("igx_cartpole_step", params, _abi.CartpoleBuffers, tensors, n_envs)
+def cartpole_step(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_cartpole_step", params, _abi.CartpoleBuffers, tensors, n_envs, cache)
 
 
-def ant_step(params, tensors, n_envs):
-    _lib.call_step("igx_ant_step", params, _abi.LocoBuffers, tensors, n_envs)
+def ant_step(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_ant_step", params, _abi.LocoBuffers, tensors, n_envs, cache)
 
 
-def humanoid_step(params, tensors, n_envs):
-    _lib.call_step("igx_humanoid_step", params, _abi.LocoBuffers, tensors, n_envs)
+def humanoid_step(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_humanoid_step", params, _abi.LocoBuffers, tensors, n_envs, cache)
 
 
 def cartpole_reset(params, tensors, env_ids):
@@ -34,22 +34,22 @@ def humanoid_reset(params, tensors, env_ids):
     _lib.call_reset("igx_humanoid_reset", params, _abi.LocoBuffers, tensors, env_ids)
 
 
-def humanoid_imitate_step(params, tensors, n_envs):
-    _lib.call_step("igx_humanoid_imitate_step", params, _abi.HumanoidImitateBuffers, tensors, n_envs)
+def humanoid_imitate_step(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_humanoid_imitate_step", params, _abi.HumanoidImitateBuffers, tensors, n_envs, cache)
 
 
-def allegro_pre_physics(params, tensors, n_envs):
-    _lib.call_step("igx_allegro_pre_physics", params, _abi.AllegroBuffers, tensors, n_envs)
+def allegro_pre_physics(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_allegro_pre_physics", params, _abi.AllegroBuffers, tensors, n_envs, cache)
 
 
-def allegro_post_physics(params, tensors, n_envs):
-    _lib.call_step("igx_allegro_post_physics", params, _abi.AllegroBuffers, tensors, n_envs)
+def allegro_post_physics(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_allegro_post_physics", params, _abi.AllegroBuffers, tensors, n_envs, cache)
 
 
-def allegro_post_physics_static(params, tensors, n_envs):
+def allegro_post_physics_static(params, tensors, n_envs, cache=None):
     """igx_allegro_post_physics with the reduction records in the library's own file-scope device
     array: allocates nothing and ignores tensors['workspace'] (n_envs <= IGX_ALLEGRO_STATIC_MAX_ENVS)."""
-    _lib.call_step("igx_allegro_post_physics_static", params, _abi.AllegroBuffers, tensors, n_envs)
+    _lib.call_step("igx_allegro_post_physics_static", params, _abi.AllegroBuffers, tensors, n_envs, cache)
 
 
 # ---- AMP motion library / HumanoidAMP ---------------------------------------
@@ -57,22 +57,25 @@ _TABLE_DTYPES = dict(motion_length=torch.float64, motion_dt=torch.float64, motio
                      frame_offset=torch.int64)
 
 
-def allegro_post_physics_shard(params, tensors, n_envs):
+def allegro_post_physics_shard(params, tensors, n_envs, cache=None):
     """One environment shard: leaves the 16-byte {num_resets, sum} record in tensors['workspace']."""
-    _lib.call_step("igx_allegro_post_physics_shard", params, _abi.AllegroBuffers, tensors, n_envs)
+    _lib.call_step("igx_allegro_post_physics_shard", params, _abi.AllegroBuffers, tensors, n_envs, cache)
 
 
-def allegro_finalize_shards(params, tensors, records):
-    """records: contiguous device tensor of num_shards x 16 bytes, gathered in rank order."""
+def allegro_finalize_shards(params, tensors, records, num_steps=1):
+    """records: contiguous device tensor of num_shards x num_steps 16-byte records, gathered in rank order
+    (shard-major); num_steps > 1 advances consecutive_successes over a queue of steps, in step order."""
     _lib.check_sizes(_abi.AllegroBuffers, params, {"consecutive_successes": tensors.get("consecutive_successes")}, 0,
                      "igx_allegro_finalize_shards")
     b, dev = _lib.make_buffers(_abi.AllegroBuffers, tensors)
     nbytes = records.numel() * records.element_size()
-    if nbytes == 0 or nbytes % 16:
-        raise ValueError("records must hold a whole number of 16-byte shard records")
+    num_steps = int(num_steps)
+    if num_steps < 1 or nbytes == 0 or nbytes % (16 * num_steps):
+        raise ValueError("records must hold a whole number of shards x %d 16-byte records" % num_steps)
     with torch.cuda.device(dev):
-        rc = _lib.lib().igx_allegro_finalize_shards(C.byref(params), C.byref(b), _lib.tensor_ptr(records),
-                                                    C.c_int32(nbytes // 16), _lib.current_stream(dev))
+        rc = _lib.lib().igx_allegro_finalize_shards_queued(C.byref(params), C.byref(b), _lib.tensor_ptr(records),
+                                                       C.c_int32(nbytes // (16 * num_steps)), C.c_int32(num_steps),
+                                                       _lib.current_stream(dev))
     _lib.check(rc)
 
 
@@ -113,30 +116,33 @@ def hand_random_forces(rb_forces, random_force_prob, reset, object_rb_handle, ob
 
 
 # ---- ShadowHand ------------------------------------------------------------------------------
-def shadow_pre_physics(params, tensors, n_envs):
-    _lib.call_step("igx_shadow_pre_physics", params, _abi.ShadowBuffers, tensors, n_envs)
+def shadow_pre_physics(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_shadow_pre_physics", params, _abi.ShadowBuffers, tensors, n_envs, cache)
 
 
-def shadow_post_physics(params, tensors, n_envs):
-    _lib.call_step("igx_shadow_post_physics", params, _abi.ShadowBuffers, tensors, n_envs)
+def shadow_post_physics(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_shadow_post_physics", params, _abi.ShadowBuffers, tensors, n_envs, cache)
 
 
-def shadow_post_physics_shard(params, tensors, n_envs):
+def shadow_post_physics_shard(params, tensors, n_envs, cache=None):
     """One environment shard: leaves the 16-byte {num_resets, sum} record in tensors['workspace']."""
-    _lib.call_step("igx_shadow_post_physics_shard", params, _abi.ShadowBuffers, tensors, n_envs)
+    _lib.call_step("igx_shadow_post_physics_shard", params, _abi.ShadowBuffers, tensors, n_envs, cache)
 
 
-def shadow_finalize_shards(params, tensors, records):
-    """records: contiguous device tensor of num_shards x 16 bytes, gathered in rank order."""
+def shadow_finalize_shards(params, tensors, records, num_steps=1):
+    """records: contiguous device tensor of num_shards x num_steps 16-byte records, gathered in rank order
+    (shard-major); num_steps > 1 advances consecutive_successes over a queue of steps, in step order."""
     _lib.check_sizes(_abi.ShadowBuffers, params, {"consecutive_successes": tensors.get("consecutive_successes")}, 0,
                      "igx_shadow_finalize_shards")
     b, dev = _lib.make_buffers(_abi.ShadowBuffers, tensors)
     nbytes = records.numel() * records.element_size()
-    if nbytes == 0 or nbytes % 16:
-        raise ValueError("records must hold a whole number of 16-byte shard records")
+    num_steps = int(num_steps)
+    if num_steps < 1 or nbytes == 0 or nbytes % (16 * num_steps):
+        raise ValueError("records must hold a whole number of shards x %d 16-byte records" % num_steps)
     with torch.cuda.device(dev):
-        rc = _lib.lib().igx_shadow_finalize_shards(C.byref(params), C.byref(b), _lib.tensor_ptr(records),
-                                                   C.c_int32(nbytes // 16), _lib.current_stream(dev))
+        rc = _lib.lib().igx_shadow_finalize_shards_queued(C.byref(params), C.byref(b), _lib.tensor_ptr(records),
+                                                       C.c_int32(nbytes // (16 * num_steps)), C.c_int32(num_steps),
+                                                       _lib.current_stream(dev))
     _lib.check(rc)
 
 
@@ -232,8 +238,8 @@ def amp_observations(root_states, dof_pos, dof_vel, key_body_pos, local_root_obs
     _lib.check(rc)
 
 
-def humanoid_amp_step(params, tensors, n_envs):
-    _lib.call_step("igx_humanoid_amp_step", params, _abi.AmpBuffers, tensors, n_envs)
+def humanoid_amp_step(params, tensors, n_envs, cache=None):
+    _lib.call_step("igx_humanoid_amp_step", params, _abi.AmpBuffers, tensors, n_envs, cache)
 
 
 def humanoid_amp_reset(params, tensors, env_ids, state):
@@ -298,12 +304,21 @@ def noise_apply(spec, x, out=None, fresh=None):
 
 
 def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0, clip_actions=float("inf"),
-                 actions_out=None, noise=None, fresh=None, num_dof=0):
+                 actions_out=None, noise=None, fresh=None, num_dof=0, cache=None):
     """Noise, clamp, copy and scaling of the actions in one launch (igx_action_stage_step).
     mode: "force" (a * gain * power_scale), "pd_target" (offset + gain * a) or
-    "first_dof" (targets[i, 0] = a[i] * power_scale, targets [N, num_dof])."""
+    "first_dof" (targets[i, 0] = a[i] * power_scale, targets [N, num_dof]).
+    `cache`: a dict owned by the caller; without noise the checked argument struct is reused while the
+    same tensors and scalars come back."""
     f = torch.float32
     dev = actions.device
+    key = None
+    if cache is not None and noise is None:
+        key = (id(actions), id(targets), id(actions_out), id(gain), id(offset), mode, power_scale, clip_actions, num_dof)
+        ent = cache.get("igx_action_stage_step")
+        if ent is not None and ent[0] == key:
+            _lib.check(_lib._launch(_lib.lib().igx_action_stage_step, dev, ent[1], ent[2]))
+            return
     modes = {"force": _abi.IGX_ACT_FORCE, "pd_target": _abi.IGX_ACT_PD_TARGET, "first_dof": _abi.IGX_ACT_FIRST_DOF}
     if mode not in modes:
         raise ValueError("mode must be one of %s" % sorted(modes))
@@ -328,9 +343,9 @@ def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0
                          num_actions=a, num_dof=int(num_dof))
     if noise is not None:
         s.noise = noise.struct(actions.numel(), fresh)
-    with torch.cuda.device(dev):
-        rc = _lib.lib().igx_action_stage_step(C.byref(s), C.c_int64(n), _lib.current_stream(dev))
-    _lib.check(rc)
+    if key is not None:
+        cache["igx_action_stage_step"] = (key, C.byref(s), C.c_int64(n), s, (actions, targets, actions_out, gain, offset))
+    _lib.check(_lib._launch(_lib.lib().igx_action_stage_step, dev, C.byref(s), C.c_int64(n)))
 
 
 def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_episode_length, states_buf=None,

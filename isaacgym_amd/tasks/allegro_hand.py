@@ -115,6 +115,7 @@ class AllegroHand(HandForcesMixin, VecTask):
         self.reset_goal_buf = self.reset_buf.clone()
         self.successes = torch.zeros(n, dtype=torch.float, device=dev)
         self.consecutive_successes = torch.zeros(1, dtype=torch.float, device=dev)
+        self._cons_scalar = self.consecutive_successes.view(())
         self.actions = torch.zeros(n, 16, device=dev)
         self.total_successes = 0
         self.total_resets = 0
@@ -172,24 +173,55 @@ class AllegroHand(HandForcesMixin, VecTask):
             self.reset_goal_buf[goal_env_ids] = 1
 
     def pre_physics_step(self, actions):
-        self.actions = actions.to(self.device).clone()
+        self.actions.copy_(actions.reshape(self.actions.shape))  # the reference clones; one persistent tensor here
         self._apply_random_forces()  # :532, :558-559, :617-625; reads reset_buf before the kernel below clears it
-        ops.allegro_pre_physics(self._params(), self._buffers(), self.num_envs)
+        ops.allegro_pre_physics(self._params(), self._buffers(), self.num_envs, self._call_cache)
         self.sim.notify_root_state(self.root_state_tensor)
         self.sim.notify_dof_state()
         self.sim.apply_dof_position_targets(self.cur_targets)
+
+    def _apply_shard_records(self, records, num_steps):
+        """consecutive_successes over a queue of gathered per-step records (runs on the queue's side stream)."""
+        ops.allegro_finalize_shards(self._build_params(), dict(consecutive_successes=self._shard_queue.pending), records,
+                                    num_steps)
+
+    def _sharded_post(self, p, b):
+        """One shard of a multi-GPU run.  The step itself exchanges nothing: its 16-byte record waits in a
+        device-side queue; every `statsSyncInterval` steps (env config, default 16; 0 = exchange on the step's
+        own stream every step, as round-trip-exact as the single-GPU value) the queues of all ranks are
+        gathered with one collective on a side stream and consecutive_successes is advanced over them in
+        step order (distributed.ShardRecordQueue)."""
+        interval = int(self.cfg["env"].get("statsSyncInterval", 16))
+        if interval <= 0:
+            ops.allegro_post_physics_shard(p, b, self.num_envs, self._call_cache)
+            records = distributed.gather_records(self._workspace.view(torch.uint8)[:16], self._group)
+            ops.allegro_finalize_shards(p, b, records)
+            return
+        q = self.__dict__.get("_shard_queue")
+        if q is None:
+            q = self._shard_queue = distributed.ShardRecordQueue(self.consecutive_successes, interval, self._group)
+        b["shard_record"] = q.slot()
+        ops.allegro_post_physics_shard(p, b, self.num_envs, self._call_cache)
+        if q.push():
+            q.flush(self._apply_shard_records)
+
+    def sync_consecutive_successes(self):
+        """Bring consecutive_successes up to the last step (sharded runs keep it up to two sync intervals behind)."""
+        q = self.__dict__.get("_shard_queue")
+        if q is not None:
+            q.drain(self._apply_shard_records)
+        return self.consecutive_successes
 
     def post_physics_step(self):
         p, b = self._params(), self._buffers()
         if self._can_fuse_tail(states_too=True):  # clamped copies and time-out flags of VecTask.step in the same launch
             self._fuse_tail(p, b)
         if distributed.world_size(self._group) > 1:
-            ops.allegro_post_physics_shard(p, b, self.num_envs)
-            records = distributed.gather_records(self._workspace.view(torch.uint8)[:16], self._group)
-            ops.allegro_finalize_shards(p, b, records)
+            self._sharded_post(p, b)
         else:
-            ops.allegro_post_physics(p, b, self.num_envs)
-        self.extras["consecutive_successes"] = self.consecutive_successes.mean()
+            ops.allegro_post_physics(p, b, self.num_envs, self._call_cache)
+        # .mean() of the one-element tensor (:393) is that element: a 0-dim view made once, no launch per step
+        self.extras["consecutive_successes"] = self._cons_scalar
         if self.print_success_stat:  # :395-404 (host prints: synchronises, as in the reference)
             self.total_resets = self.total_resets + self.reset_buf.sum()
             direct = self.total_successes + self.successes.sum()

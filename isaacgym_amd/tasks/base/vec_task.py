@@ -44,6 +44,9 @@ class VecTask:
             raise ValueError("isaacgym_amd runs on a GPU only (sim_device=%r); there is no CPU pipeline" % sim_device)
         self.device = "cuda:%d" % self.device_id
         self.rl_device = rl_device
+        self._tdev = torch.device(self.device)
+        # rl_device == sim device (the default): what step() returns needs no .to(); checked once, not per tensor per step
+        self._rl_same = torch.device(rl_device) == self._tdev
         self.headless = headless
         self.graphics_device_id = graphics_device_id
         self.virtual_screen_capture = virtual_screen_capture
@@ -165,6 +168,14 @@ class VecTask:
     # shards, the in-kernel draws of a shard are those of the unsharded run (distributed.env_shard gives it)
     env_offset = 0
 
+    @property
+    def _call_cache(self):
+        """Validated argument structs of this task's step calls, kept between steps (isaacgym_amd._lib.call_step)."""
+        c = self.__dict__.get("_call_cache_dict")
+        if c is None:
+            c = self.__dict__["_call_cache_dict"] = {}
+        return c
+
     def _rng_dev(self):
         """Address of the device-resident draw counter, or None.  isaacgym_amd.graph.GraphedStep installs the
         counter: a replayed graph repeats the by-value rng_offset, the counter keeps the draws fresh."""
@@ -252,12 +263,14 @@ class VecTask:
         (self.actions) and scaling into `targets` in one launch, which also carries the action
         noise and clamp when the call comes from step()."""
         stage, self._stage = (self._stage or {}), None
-        actions = actions.to(self.device, torch.float32).contiguous()
+        if actions.device != self._tdev or actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(self.device, torch.float32).contiguous()
         ops.action_stage(actions, targets, mode, gain=gain, offset=offset, power_scale=power_scale, num_dof=num_dof,
-                         actions_out=keep, **stage)
+                         actions_out=keep, cache=self._call_cache, **stage)
 
     def step(self, actions):
-        actions = actions.to(self.device, torch.float32).contiguous()
+        if actions.device != self._tdev or actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(self.device, torch.float32).contiguous()
         if actions.numel() != self._action_tensor.numel():
             raise ValueError("expected %d x %d actions, got %s" % (self.num_envs, self.num_actions, tuple(actions.shape)))
         if self.FUSED_ACTION_STAGE:
@@ -281,6 +294,12 @@ class VecTask:
                               self._states_out if self.num_states > 0 else None,
                               obs_noised=self.obs_buf if stage else None, **stage)
         self.timeout_buf = self._time_outs
+        if self._rl_same:
+            self.extras["time_outs"] = self.timeout_buf
+            self.obs_dict["obs"] = self._obs_out
+            if self.num_states > 0:
+                self.obs_dict["states"] = self._states_out
+            return self.obs_dict, self.rew_buf, self.reset_buf, self.extras
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.obs_dict["obs"] = self._obs_out.to(self.rl_device)
         if self.num_states > 0:

@@ -49,7 +49,7 @@ class Cartpole(VecTask):
         self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
-        ops.cartpole_step(self._params(), self._buffers(), self.num_envs)
+        ops.cartpole_step(self._params(), self._buffers(), self.num_envs, self._call_cache)
 
     def reset_idx(self, env_ids):
         ops.cartpole_reset(self._params(), self._buffers(), env_ids.to(self.device, torch.int64).contiguous())

@@ -148,7 +148,7 @@ class HumanoidAMPBase(VecTask):
         p, b = self._params(), self._buffers()
         if self._can_fuse_tail():  # clamped copy and time-out flags of VecTask.step in the same launch
             self._fuse_tail(p, b)
-        ops.humanoid_amp_step(p, b, self.num_envs)
+        ops.humanoid_amp_step(p, b, self.num_envs, self._call_cache)
         self.extras["terminate"] = self._terminate_buf
 
     def reset_idx(self, env_ids):  # humanoid_amp_base.py:165-169, :392-408

@@ -95,7 +95,7 @@ class HumanoidImitate(VecTask):
         p, b = self._params(), self._buffers()
         if self._can_fuse_tail():  # clamped copy and time-out flags of VecTask.step in the same launch
             self._fuse_tail(p, b)
-        ops.humanoid_imitate_step(p, b, self.num_envs)
+        ops.humanoid_imitate_step(p, b, self.num_envs, self._call_cache)
 
     def reset_idx(self, env_ids):
         """reset_idx on an id list = the flagged reset of the step kernel: raise the flags; they are

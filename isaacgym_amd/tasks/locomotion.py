@@ -132,7 +132,7 @@ class LocomotionTask(VecTask):
         p, b = self._params(), self._buffers()
         if self._can_fuse_tail():  # the clamped copy and the time-out flags of VecTask.step in the same launch
             self._fuse_tail(p, b)
-        self._step_kernel(p, b, self.num_envs)
+        self._step_kernel(p, b, self.num_envs, self._call_cache)
         if not self.HUMANOID:
             self.extras["true_objective"] = self._true_objective  # ant.py:332-337
 

@@ -1153,7 +1153,22 @@ int orc_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buff
 /* one shard of an environment-sharded run: the record goes to b->workspace */
 int orc_allegro_post_physics_shard(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n)
 {
-    return allegro_post(p, b, n, (allegro_record *)b->workspace);
+    int rc = allegro_post(p, b, n, (allegro_record *)b->workspace);
+    if (rc == 0 && b->shard_record) *(allegro_record *)b->shard_record = *(const allegro_record *)b->workspace;
+    return rc;
+}
+
+/* a queue of steps: records[shard * num_steps + step], applied strictly in step order */
+int orc_allegro_finalize_shards_queued(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
+                                       int32_t num_shards, int32_t num_steps)
+{
+    const allegro_record *r = (const allegro_record *)records;
+    for (int t = 0; t < num_steps; ++t) {
+        allegro_record step[num_shards];
+        for (int i = 0; i < num_shards; ++i) step[i] = r[(int64_t)i * num_steps + t];
+        allegro_finalize(p, b, step, num_shards);
+    }
+    return 0;
 }
 
 int orc_allegro_finalize_shards(const igx_allegro_params *p, const igx_allegro_buffers *b, const void *records,
@@ -1367,7 +1382,21 @@ int orc_shadow_post_physics(const igx_shadow_params *p, const igx_shadow_buffers
 
 int orc_shadow_post_physics_shard(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n)
 {
-    return shadow_post(p, b, n, (allegro_record *)b->workspace);
+    int rc = shadow_post(p, b, n, (allegro_record *)b->workspace);
+    if (rc == 0 && b->shard_record) *(allegro_record *)b->shard_record = *(const allegro_record *)b->workspace;
+    return rc;
+}
+
+int orc_shadow_finalize_shards_queued(const igx_shadow_params *p, const igx_shadow_buffers *b, const void *records,
+                                      int32_t num_shards, int32_t num_steps)
+{
+    const allegro_record *r = (const allegro_record *)records;
+    for (int t = 0; t < num_steps; ++t) {
+        allegro_record step[num_shards];
+        for (int i = 0; i < num_shards; ++i) step[i] = r[(int64_t)i * num_steps + t];
+        shadow_finalize(p, b, step, num_shards);
+    }
+    return 0;
 }
 
 int orc_shadow_finalize_shards(const igx_shadow_params *p, const igx_shadow_buffers *b, const void *records, int32_t num_shards)

@@ -101,12 +101,13 @@ def allegro_post_physics_shard(params, bufs, n):
     _call(lib().orc_allegro_post_physics_shard, params, _abi.AllegroBuffers, bufs, n)
 
 
-def allegro_finalize_shards(params, bufs, records):
-    """records: uint8 array [num_shards, 16] gathered in rank order."""
-    records = np.ascontiguousarray(records, np.uint8)
+def allegro_finalize_shards(params, bufs, records, num_steps=1):
+    """records: uint8 array of num_shards x num_steps 16-byte records, shard-major, gathered in rank order."""
+    records = np.ascontiguousarray(records, np.uint8).reshape(-1)
     b = _abi.make_buffers(_abi.AllegroBuffers, bufs, _np_ptr)
-    assert lib().orc_allegro_finalize_shards(C.byref(params), C.byref(b), C.c_void_p(records.ctypes.data),
-                                             C.c_int32(records.shape[0])) == 0
+    assert records.size % (16 * num_steps) == 0 and records.size
+    assert lib().orc_allegro_finalize_shards_queued(C.byref(params), C.byref(b), C.c_void_p(records.ctypes.data),
+                                                C.c_int32(records.size // (16 * num_steps)), C.c_int32(num_steps)) == 0
 
 
 # ---- ShadowHand --------------------------------------------------------------
@@ -122,11 +123,13 @@ def shadow_post_physics_shard(params, bufs, n):
     _call(lib().orc_shadow_post_physics_shard, params, _abi.ShadowBuffers, bufs, n)
 
 
-def shadow_finalize_shards(params, bufs, records):
-    records = np.ascontiguousarray(records, np.uint8)
+def shadow_finalize_shards(params, bufs, records, num_steps=1):
+    """records: uint8 array of num_shards x num_steps 16-byte records, shard-major, gathered in rank order."""
+    records = np.ascontiguousarray(records, np.uint8).reshape(-1)
     b = _abi.make_buffers(_abi.ShadowBuffers, bufs, _np_ptr)
-    assert lib().orc_shadow_finalize_shards(C.byref(params), C.byref(b), C.c_void_p(records.ctypes.data),
-                                            C.c_int32(records.shape[0])) == 0
+    assert records.size % (16 * num_steps) == 0 and records.size
+    assert lib().orc_shadow_finalize_shards_queued(C.byref(params), C.byref(b), C.c_void_p(records.ctypes.data),
+                                                C.c_int32(records.size // (16 * num_steps)), C.c_int32(num_steps)) == 0
 
 
 # ---- AMP motion library / observations ------------------------------------

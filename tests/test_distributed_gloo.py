@@ -206,3 +206,65 @@ def test_quantile_sharded_over_two_gloo_ranks_equals_torch(tmp_path):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "q%d.npy" % r))
         assert np.array_equal(got, want), (r, got, want)
+
+
+def _queued_rank(rank, world, port, n, outdir, which):
+    """The same sharded run twice: the record exchange on every step, and queued (distributed.ShardRecordQueue:
+    one gather per `interval` steps, applied in step order) - consecutive_successes must come out bit-identical."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    oracle.set_num_threads(2)
+    start, count = distributed.env_shard(n, rank, world)
+    if which == "allegro":
+        full = {k: (v.numpy().copy() if v is not None else None)
+                for k, v in synthetic.allegro_state(n, 31, "cpu", "full_state", True).items()}
+        full["rand"] = np.random.default_rng(1).random((n, 45), dtype=np.float32)
+        p = synthetic.allegro_params("full_state")
+        pre, shard, fin = oracle.allegro_pre_physics, oracle.allegro_post_physics_shard, oracle.allegro_finalize_shards
+    else:
+        full = _shadow_state(n)
+        p = synthetic.shadow_params("full")
+        pre, shard, fin = oracle.shadow_pre_physics, oracle.shadow_post_physics_shard, oracle.shadow_finalize_shards
+    steps, interval = 7, 3   # two full horizons and a partial one
+    a = _slice_state(full, start, count)
+    per_step = []
+    for step in range(steps):
+        a["reset"][step::5] = 1  # keep episodes finishing so the average keeps moving
+        pre(p, a, count)
+        shard(p, a, count)
+        fin(p, a, distributed.gather_records(torch.from_numpy(a["workspace"].view(np.uint8)[:16].copy())).numpy())
+        per_step.append(a["consecutive_successes"].copy())
+    b = _slice_state(full, start, count)
+    visible = torch.from_numpy(b["consecutive_successes"])
+    q = distributed.ShardRecordQueue(visible, interval)
+    apply = lambda records, k: fin(p, dict(consecutive_successes=q.pending.numpy()), records.numpy().view(np.uint8), k)
+    seen = []
+    for step in range(steps):
+        b["reset"][step::5] = 1
+        pre(p, b, count)
+        b["shard_record"] = q.slot().numpy()
+        shard(p, b, count)
+        if q.push():
+            q.flush(apply)
+        seen.append(visible.numpy().copy())
+    assert q.flushes == steps // interval
+    # visible lags: after the flush at the end of horizon h it shows the state after horizon h - 1
+    assert np.array_equal(seen[2], np.zeros(1, np.float32))
+    assert np.array_equal(seen[5].view(np.uint32), per_step[2].view(np.uint32))
+    q.drain(apply)
+    assert np.array_equal(visible.numpy().view(np.uint32), per_step[-1].view(np.uint32))  # the per-step path's bits
+    assert per_step[-1][0] != 0.0
+    for k in ("obs", "rew", "reset", "progress", "successes"):
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+    np.save(os.path.join(outdir, "cons%d.npy" % rank), visible.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["allegro", "shadow"])
+def test_queued_shard_records_equal_the_per_step_exchange(tmp_path, which):
+    world = 2
+    mp.spawn(_queued_rank, args=(world, _free_port(), 1501, str(tmp_path), which), nprocs=world, join=True)
+    cons = [np.load(os.path.join(str(tmp_path), "cons%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(cons[0].view(np.uint32), cons[1].view(np.uint32))

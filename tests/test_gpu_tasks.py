@@ -551,3 +551,43 @@ def test_resets_re_randomise_like_the_reference(name):
     task.reset_buf[5] = 1
     task.step(torch.zeros(n, 8, device=DEV))
     assert len(calls) == quiet + 1
+
+
+@pytest.mark.parametrize("name,nact", [("AllegroHand", 16), ("ShadowHand", 20)])
+def test_sharded_hand_keeps_collectives_off_the_task_stream(name, nact, monkeypatch):
+    """A sharded hand task exchanges its records once per statsSyncInterval steps, on a side stream: no collective
+    is enqueued on the task's stream between two step() calls, and after sync_consecutive_successes() the value
+    is bit for bit that of exchanging on every step."""
+    from isaacgym_amd import distributed
+    calls = []
+    task_stream = torch.cuda.current_stream(DEV)
+
+    def fake_gather(record, group=None):  # a world of two identical shards
+        calls.append((torch.cuda.current_stream(DEV).cuda_stream, record.numel()))
+        return torch.stack([record.reshape(-1), record.reshape(-1)])
+
+    monkeypatch.setattr(distributed, "world_size", lambda group=None: 2)
+    monkeypatch.setattr(distributed, "gather_records", fake_gather)
+    n, steps = 2000, 9
+    queued = tasks.make(name, n, DEV, seed=4, statsSyncInterval=4)
+    direct = tasks.make(name, n, DEV, seed=4, statsSyncInterval=0)
+    g = torch.Generator().manual_seed(1)
+    for step in range(steps):
+        a = (torch.rand(n, nact, generator=g) * 2 - 1).to(DEV)
+        for t in (queued, direct):
+            t.successes.add_(1.0)  # something for the average to move on:
+            t.progress_buf[step::50] = t.max_episode_length - 2   # ... episodes that end this step
+        before = len(calls)
+        queued.step(a)
+        made = calls[before:]
+        assert len(made) == (1 if step % 4 == 3 else 0), step      # one exchange per four steps ...
+        assert all(s != task_stream.cuda_stream for s, _ in made)   # ... and never on the task's stream
+        direct.step(a)
+        assert calls[-1][0] == task_stream.cuda_stream              # the per-step path does use it
+        for k in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "successes"):
+            assert torch.equal(getattr(queued, k), getattr(direct, k)), (k, step)
+    assert float(queued.consecutive_successes) != float(direct.consecutive_successes)  # still behind
+    queued.sync_consecutive_successes()
+    torch.cuda.synchronize()
+    assert torch.equal(queued.consecutive_successes.view(torch.int32), direct.consecutive_successes.view(torch.int32))
+    assert float(direct.consecutive_successes) != 0.0

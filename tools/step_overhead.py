@@ -28,6 +28,18 @@ for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 
     wall = (time.perf_counter() - t0) / k * 1e6
     line = ("%-12s n=%8d  host %.1f us/step  wall %.1f us/step  device span %.1f us/step" %
             (name, n, host, wall, e0.elapsed_time(e1) / k * 1e3))
+    # the stand-in simulator copies a fresh state set into the shared tensors every simulate(); with an engine
+    # that writes its tensors in place (here: a simulate() that does nothing) the step is this package's code alone
+    t2 = tasks.make(name, n, DEV)
+    t2.sim.simulate = lambda: None
+    for _ in range(20):
+        t2.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        t2.step(a)
+    torch.cuda.synchronize()
+    line += "  | in-place sim: wall %.1f us/step" % ((time.perf_counter() - t0) / k * 1e6)
     # the same step recorded once into a HIP graph and replayed
     g = GraphedStep(tasks.make(name, n, DEV))
     for _ in range(20):
