@@ -317,6 +317,7 @@ typedef struct igx_allegro_params {
     float goal_displacement[3];   /* (-0.2, -0.06, 0.12) */
     float dof_lower[IGX_ALLEGRO_DOF], dof_upper[IGX_ALLEGRO_DOF];
     float clip_obs;               /* env.clipObservations (+inf copies); read only with obs_clamped / states_clamped */
+    float clip_actions;           /* pre_physics with actions_out: env.clipActions (+inf copies) */
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
     int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
@@ -355,6 +356,10 @@ typedef struct igx_allegro_buffers {
     uint8_t *time_outs;               /* [N] bool (progress >= episodeLength - 1) & (reset != 0) after the step */
     void *shard_record;               /* igx_*_post_physics_shard only, optional: the call's 16-byte record is ALSO written here
                                          (a slot of a caller-side queue of records, one per step) */
+    float *actions_out;               /* pre_physics only, optional: the clamp of VecTask.step (tasks/base/vec_task.py:384) folded
+                                         into this launch - `actions` then holds what step() was handed, clamp(actions,
+                                         -clip_actions, clip_actions) is written here (the task's self.actions) and is what
+                                         the targets are computed from.  NULL: `actions` is used as it is. */
 } igx_allegro_buffers;
 
 int igx_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffers *b,
@@ -439,6 +444,7 @@ typedef struct igx_shadow_params {
     int32_t actuated_dof_indices[IGX_SHADOW_ACTIONS]; /* strictly increasing, in [0, 24) */
     int32_t fingertip_handles[IGX_SHADOW_FINGERTIPS]; /* body indices in [0, num_bodies) */
     float clip_obs;                    /* as in igx_allegro_params */
+    float clip_actions;           /* pre_physics with actions_out: env.clipActions (+inf copies) */
     uint64_t seed, rng_offset;
     const uint64_t *rng_offset_dev; /* as in igx_cartpole_params */
     int64_t env_offset;             /* index of this call's first environment in the whole job (0 on one GPU): added to the
@@ -473,6 +479,10 @@ typedef struct igx_shadow_buffers {
     uint8_t *time_outs;
     void *shard_record;               /* igx_*_post_physics_shard only, optional: the call's 16-byte record is ALSO written here
                                          (a slot of a caller-side queue of records, one per step) */
+    float *actions_out;               /* pre_physics only, optional: the clamp of VecTask.step (tasks/base/vec_task.py:384) folded
+                                         into this launch - `actions` then holds what step() was handed, clamp(actions,
+                                         -clip_actions, clip_actions) is written here (the task's self.actions) and is what
+                                         the targets are computed from.  NULL: `actions` is used as it is. */
 } igx_shadow_buffers;
 
 int igx_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers *b, int64_t n_envs, igx_stream_t stream);

@@ -100,7 +100,8 @@ class AllegroParams(_Struct):
                 ("dof_speed_scale_dt", f32),
                 ("goal_displacement", f32 * 3),
                 ("dof_lower", f32 * IGX_ALLEGRO_DOF), ("dof_upper", f32 * IGX_ALLEGRO_DOF),
-                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
+                ("clip_obs", f32), ("clip_actions", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr),
+                ("env_offset", i64)]
 
 
 class AllegroBuffers(_Struct):
@@ -111,7 +112,7 @@ class AllegroBuffers(_Struct):
                 ("obs", ptr), ("states", ptr), ("rew", ptr),
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
                 ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr),
-                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr), ("shard_record", ptr)]
+                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr), ("shard_record", ptr), ("actions_out", ptr)]
 
 IGX_SHADOW_DOF, IGX_SHADOW_ACTIONS, IGX_SHADOW_FINGERTIPS, IGX_SHADOW_RAND_PER_ENV = 24, 20, 5, 61
 IGX_SHADOW_OBS = {"openai": 0, "full_no_vel": 1, "full": 2, "full_state": 3}
@@ -134,7 +135,8 @@ class ShadowParams(_Struct):
                 ("goal_displacement", f32 * 3), ("num_bodies", i32),
                 ("dof_lower", f32 * IGX_SHADOW_DOF), ("dof_upper", f32 * IGX_SHADOW_DOF),
                 ("actuated_dof_indices", i32 * IGX_SHADOW_ACTIONS), ("fingertip_handles", i32 * IGX_SHADOW_FINGERTIPS),
-                ("clip_obs", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
+                ("clip_obs", f32), ("clip_actions", f32), ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr),
+                ("env_offset", i64)]
 
 
 class ShadowBuffers(_Struct):
@@ -145,7 +147,7 @@ class ShadowBuffers(_Struct):
                 ("obs", ptr), ("states", ptr), ("rew", ptr),
                 ("reset", ptr), ("reset_goal", ptr), ("progress", ptr), ("randomize", ptr),
                 ("successes", ptr), ("consecutive_successes", ptr), ("workspace", ptr),
-                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr), ("shard_record", ptr)]
+                ("obs_clamped", ptr), ("states_clamped", ptr), ("time_outs", ptr), ("shard_record", ptr), ("actions_out", ptr)]
 
 
 IGX_HAND_FORCE_RAND_PER_ENV = 5
@@ -334,7 +336,7 @@ def _hand_widths(dof, actions, rand, nobs, nstates, extra):
              actions=_env(actions), prev_targets=_env(dof), cur_targets=_env(dof), rand=_env(rand), obs=_env(nobs),
              states=_env(nstates), rew=_ONE, reset=_ONE, reset_goal=_ONE, progress=_ONE, randomize=_ONE,
              successes=_ONE, consecutive_successes=("fixed", 1), workspace=("bytes", IGX_ALLEGRO_WORKSPACE_BYTES),
-             obs_clamped=_env(nobs), states_clamped=_env(nstates), time_outs=_ONE, shard_record=("bytes", lambda n: 16))
+             obs_clamped=_env(nobs), states_clamped=_env(nstates), time_outs=_ONE, shard_record=("bytes", lambda n: 16), actions_out=_env(actions))
     w.update(extra)
     return w
 

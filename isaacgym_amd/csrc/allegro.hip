@@ -82,6 +82,15 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
         v4f r[AD / 4];
         load_chunks<WAVE * AD / 4>(b.prev_targets + base * AD, r, lane);
         load_chunks<WAVE * AD / 4>(b.actions + base * AD, act, lane);
+        if (b.actions_out) {  // VecTask.step's clamp, folded in: self.actions receives the clamped actions
+            const float hi = p.clip_actions, lo = -p.clip_actions;
+#pragma unroll
+            for (int it = 0; it < AD / 4; ++it) {
+                act[it].x = clamp1(act[it].x, lo, hi); act[it].y = clamp1(act[it].y, lo, hi);
+                act[it].z = clamp1(act[it].z, lo, hi); act[it].w = clamp1(act[it].w, lo, hi);
+                st_stream(reinterpret_cast<v4f *>(b.actions_out + base * AD) + lane + it * WAVE, act[it]);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < AD / 4; ++it) *reinterpret_cast<v4f *>(s_prev + 4 * (lane + it * WAVE)) = r[it];
     } else {
@@ -146,7 +155,12 @@ __global__ __launch_bounds__(WAVE) void allegro_pre_kernel(const igx_allegro_par
     } else {
         for (int i = lane; i < count; i += WAVE) {
             const int j = i & (AD - 1);
-            const float c = target(b.actions[base * AD + i], s_prev[i], s_lim[j], s_lim[AD + j]);
+            float a = b.actions[base * AD + i];
+            if (b.actions_out) {
+                a = clamp1(a, -p.clip_actions, p.clip_actions);
+                b.actions_out[base * AD + i] = a;
+            }
+            const float c = target(a, s_prev[i], s_lim[j], s_lim[AD + j]);
             b.cur_targets[base * AD + i] = c;
             b.prev_targets[base * AD + i] = c;
         }
@@ -319,6 +333,10 @@ static int check_allegro(const igx_allegro_params *p, const igx_allegro_buffers 
         REQ(object_init_state, false);
         REQ(prev_targets, true);
         REQ(cur_targets, true);
+        if (b->actions_out) {
+            if (!aligned16(b->actions_out)) return fail(IGX_E_ALIGN, "%s: actions_out must be 16-byte aligned", who);
+            if (!(p->clip_actions >= 0.0f)) return fail(IGX_E_PARAM, "%s: clip_actions must be >= 0 with actions_out", who);
+        }
     }
 #undef REQ
     return IGX_OK;

@@ -96,6 +96,13 @@ __global__ __launch_bounds__(WAVE) void shadow_pre_kernel(const igx_shadow_param
         load_chunks<WAVE * SD / 4>(b.cur_targets + base * SD, rc, lane);
 #pragma unroll
         for (int it = 0; it < SA; ++it) r_act[it] = ld_stream(b.actions + base * SA + lane + it * WAVE);
+        if (b.actions_out) {  // VecTask.step's clamp, folded in: self.actions receives the clamped actions
+#pragma unroll
+            for (int it = 0; it < SA; ++it) {
+                r_act[it] = clamp1(r_act[it], -p.clip_actions, p.clip_actions);
+                st_stream(b.actions_out + base * SA + lane + it * WAVE, r_act[it]);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < SD / 4; ++it) {
             *reinterpret_cast<v4f *>(s_prev + 4 * (lane + it * WAVE)) = rp[it];
@@ -157,7 +164,12 @@ __global__ __launch_bounds__(WAVE) void shadow_pre_kernel(const igx_shadow_param
     } else {
         for (int i = lane; i < nvalid * SA; i += WAVE) {
             const int env = i / SA, a = i - env * SA, j = s_idx[a];
-            const float c = joint_target(p, b.actions[base * SA + i], s_prev[env * SD + j], s_lim[j], s_lim[SD + j]);
+            float act = b.actions[base * SA + i];
+            if (b.actions_out) {
+                act = clamp1(act, -p.clip_actions, p.clip_actions);
+                b.actions_out[base * SA + i] = act;
+            }
+            const float c = joint_target(p, act, s_prev[env * SD + j], s_lim[j], s_lim[SD + j]);
             s_cur[env * SD + j] = c;
             s_prev[env * SD + j] = c;
         }
@@ -411,6 +423,8 @@ static int check_shadow(const igx_shadow_params *p, const igx_shadow_buffers *b,
         REQ(object_init_state, false);
         REQ(prev_targets, true);
         REQ(cur_targets, true);
+        if (b->actions_out && !(p->clip_actions >= 0.0f))
+            return fail(IGX_E_PARAM, "%s: clip_actions must be >= 0 with actions_out", who);
     }
 #undef REQ
     return IGX_OK;

@@ -349,13 +349,21 @@ def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0
 
 
 def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_episode_length, states_buf=None,
-                  states_out=None, noise=None, fresh=None, obs_noised=None):
+                  states_out=None, noise=None, fresh=None, obs_noised=None, cache=None):
     """obs_out = clamp(obs_buf, +-clip_obs); states likewise; time_outs (torch.bool) =
     (progress >= max_episode_length - 1) & (reset != 0).  With `noise` (a NoiseSpec) the
     observation noise is applied before the clamp and the noised buffer kept in
     `obs_noised` (may be obs_buf itself)."""
     f = torch.float32
     dev = obs_buf.device
+    key = None
+    if cache is not None and noise is None:  # without noise nothing in the struct changes between steps
+        key = (id(obs_buf), id(obs_out), id(progress), id(reset), id(time_outs), id(states_buf), id(states_out),
+               clip_obs, max_episode_length)
+        ent = cache.get("igx_vec_task_tail_step")
+        if ent is not None and ent[0] == key:
+            _lib.check(_lib._launch(_lib.lib().igx_vec_task_tail_step, dev, ent[1], ent[2]))
+            return
     t = _abi.VecTaskTail()
     t.obs_buf, t.obs_out, t.obs_count = _lib.tensor_ptr(obs_buf, f), _lib.tensor_ptr(obs_out, f), obs_buf.numel()
     if obs_out.numel() != obs_buf.numel():
@@ -378,19 +386,18 @@ def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_ep
     t.time_outs = _lib.tensor_ptr(time_outs, torch.bool)
     t.max_episode_length_m1 = float(max_episode_length - 1)
     t.clip_obs = float(clip_obs)
-    with torch.cuda.device(dev):
-        rc = _lib.lib().igx_vec_task_tail_step(C.byref(t), C.c_int64(n), _lib.current_stream(dev))
-    _lib.check(rc)
+    if key is not None:
+        cache["igx_vec_task_tail_step"] = (key, C.byref(t), C.c_int64(n), t,
+                                           (obs_buf, obs_out, progress, reset, time_outs, states_buf, states_out))
+    _lib.check(_lib._launch(_lib.lib().igx_vec_task_tail_step, dev, C.byref(t), C.c_int64(n)))
 
 
 def clamp(x, lo, hi, out):
     dev = x.device
     if out.numel() != x.numel():
         raise ValueError("out must have as many elements as x")
-    with torch.cuda.device(dev):
-        rc = _lib.lib().igx_clamp(_lib.tensor_ptr(x, torch.float32), C.c_float(lo), C.c_float(hi),
-                                  _lib.tensor_ptr(out, torch.float32), C.c_int64(x.numel()), _lib.current_stream(dev))
-    _lib.check(rc)
+    _lib.check(_lib._launch(_lib.lib().igx_clamp, dev, _lib.tensor_ptr(x, torch.float32), C.c_float(lo), C.c_float(hi),
+                            _lib.tensor_ptr(out, torch.float32), C.c_int64(x.numel())))
 
 
 # ---- AntImitate / global quantile ---------------------------------------------------------

@@ -117,6 +117,7 @@ class AllegroHand(HandForcesMixin, VecTask):
         self.consecutive_successes = torch.zeros(1, dtype=torch.float, device=dev)
         self._cons_scalar = self.consecutive_successes.view(())
         self.actions = torch.zeros(n, 16, device=dev)
+        self._action_tensor = self.actions  # VecTask.step's clamp writes the task's own action tensor: no second copy
         self.total_successes = 0
         self.total_resets = 0
         self.seed = int(seed)
@@ -172,10 +173,21 @@ class AllegroHand(HandForcesMixin, VecTask):
         if goal_env_ids is not None and len(goal_env_ids) > 0:
             self.reset_goal_buf[goal_env_ids] = 1
 
+    FUSED_ACTION_STAGE = True  # step() leaves the clamp of the actions to the pre-physics launch
+
     def pre_physics_step(self, actions):
-        self.actions.copy_(actions.reshape(self.actions.shape))  # the reference clones; one persistent tensor here
-        self._apply_random_forces()  # :532, :558-559, :617-625; reads reset_buf before the kernel below clears it
-        ops.allegro_pre_physics(self._params(), self._buffers(), self.num_envs, self._call_cache)
+        stage, self._stage = self._stage, None
+        p, b = self._params(), self._buffers()
+        if stage is not None and "noise" not in stage:   # called from step(): raw actions, clamp folded into the kernel
+            b["actions"], b["actions_out"] = actions, self.actions
+            p.clip_actions = float(stage["clip_actions"])
+        elif stage is not None:                          # action noise configured: noise, then the clamp
+            noised = ops.noise_apply(stage["noise"], actions, fresh=stage.get("fresh"))
+            ops.clamp(noised, -stage["clip_actions"], stage["clip_actions"], self.actions)
+        elif actions is not self.actions:                # a direct call: the actions are taken as they are
+            self.actions.copy_(actions.reshape(self.actions.shape))
+        self._apply_random_forces()  # reads reset_buf before the kernel below clears it
+        ops.allegro_pre_physics(p, b, self.num_envs, self._call_cache)
         self.sim.notify_root_state(self.root_state_tensor)
         self.sim.notify_dof_state()
         self.sim.apply_dof_position_targets(self.cur_targets)

@@ -148,14 +148,25 @@ class VecTask:
     def _build_params(self):
         raise NotImplementedError
 
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        cls._PARAM_KEY_SET = frozenset(cls._PARAM_KEY)
+
+    _PARAM_KEY_SET = frozenset()
+
+    def __setattr__(self, name, value):
+        # assigning one of the attributes the parameter struct is built from drops the kept struct
+        if name in self._PARAM_KEY_SET:
+            object.__setattr__(self, "_ptmpl", None)
+        object.__setattr__(self, name, value)
+
     def _params(self):
         """This step's parameter struct.  Filling a ctypes struct with array members costs tens of
         microseconds, so the filled struct is kept and copied until one of the attributes it was
-        built from changes (the reference reads them every step: changing one still takes effect)."""
+        built from is assigned again (the reference reads them every step: changing one still takes effect)."""
         self._draws += 1
-        key = tuple([getattr(self, k) for k in self._PARAM_KEY])
-        if key != getattr(self, "_ptmpl_key", None):
-            self._ptmpl, self._ptmpl_key = self._build_params(), key
+        if self.__dict__.get("_ptmpl") is None:
+            object.__setattr__(self, "_ptmpl", self._build_params())
         p = type(self._ptmpl)()
         C.memmove(C.byref(p), C.byref(self._ptmpl), C.sizeof(p))
         p.rng_offset = self._draws
@@ -292,7 +303,7 @@ class VecTask:
                               self._time_outs, self.max_episode_length,
                               self.states_buf if self.num_states > 0 else None,
                               self._states_out if self.num_states > 0 else None,
-                              obs_noised=self.obs_buf if stage else None, **stage)
+                              obs_noised=self.obs_buf if stage else None, cache=self._call_cache, **stage)
         self.timeout_buf = self._time_outs
         if self._rl_same:
             self.extras["time_outs"] = self.timeout_buf

@@ -1014,6 +1014,11 @@ int orc_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffe
         }
         for (int j = 0; j < D; ++j) {
             float a = b->actions[e * D + j], lo = p->dof_lower[j], hi = p->dof_upper[j], c;
+            if (b->actions_out) {  /* tasks/base/vec_task.py:384: torch.clamp(actions, -clip, clip), kept as self.actions */
+                a = a < -p->clip_actions ? -p->clip_actions : a;
+                a = a > p->clip_actions ? p->clip_actions : a;
+                b->actions_out[e * D + j] = a;
+            }
             if (p->use_relative_control) {
                 c = b->prev_targets[e * D + j] + p->dof_speed_scale_dt * a;
                 c = fmaxf(fminf(c, hi), lo);
@@ -1238,6 +1243,11 @@ int orc_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers 
         for (int a = 0; a < A; ++a) { /* :684-697, actuated joints only */
             const int j = p->actuated_dof_indices[a];
             float x = b->actions[e * A + a], lo = p->dof_lower[j], hi = p->dof_upper[j], c;
+            if (b->actions_out) {  /* tasks/base/vec_task.py:384 */
+                x = x < -p->clip_actions ? -p->clip_actions : x;
+                x = x > p->clip_actions ? p->clip_actions : x;
+                b->actions_out[e * A + a] = x;
+            }
             if (p->use_relative_control) {
                 c = b->prev_targets[e * D + j] + p->dof_speed_scale_dt * x;
                 c = fmaxf(fminf(c, hi), lo);
