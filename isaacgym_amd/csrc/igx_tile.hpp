@@ -35,6 +35,7 @@ __device__ __forceinline__ void st_narrow(T *p, T v) { *p = v; }
 
 __device__ __forceinline__ v4f ld_stream_u(const float *p)
 {
+    // (16-byte gathers keep the nt policy: plain loads measured 5-12 % slower on the hand, AMP and imitation steps)
     return __builtin_nontemporal_load(reinterpret_cast<const v4f_u *>(p));
 }
 

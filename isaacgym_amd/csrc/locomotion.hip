@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void imitate_finish_kernel(const igx_loco_buff
     const double q = reinterpret_cast<const double *>(im.workspace)[5];  // QuantileState::result
     // Python's max(1.8, quantile): the quantile only if it compares greater - a NaN quantile leaves 1.8
     const double thr = q > im.distance_floor ? q : im.distance_floor;
-    const double d = ld_stream(im.pose_diff + e);
+    const double d = ld_narrow(im.pose_diff + e);
     int64_t idx = im.target_pose_idx[e];
     const bool far = d > thr;
     const bool finished = (far ? 0 : idx) >= im.num_frames - 3;

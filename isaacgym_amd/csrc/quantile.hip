@@ -159,11 +159,11 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const double *__rest
     for (; i + (U - 1) * stride < n; i += U * stride) {
         double v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = ld_stream(x + i + u * stride);
+        for (int u = 0; u < U; ++u) v[u] = ld_narrow(x + i + u * stride);
 #pragma unroll
         for (int u = 0; u < U; ++u) count(v[u]);
     }
-    for (; i < n; i += stride) count(ld_stream(x + i));
+    for (; i < n; i += stride) count(ld_narrow(x + i));
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * QBINS; i += 256) {
         const unsigned c = (&s_hist[0][0])[i];

@@ -95,12 +95,12 @@ __global__ __launch_bounds__(WAVE) void shadow_pre_kernel(const igx_shadow_param
         load_chunks<WAVE * SD / 4>(b.prev_targets + base * SD, rp, lane);
         load_chunks<WAVE * SD / 4>(b.cur_targets + base * SD, rc, lane);
 #pragma unroll
-        for (int it = 0; it < SA; ++it) r_act[it] = ld_stream(b.actions + base * SA + lane + it * WAVE);
+        for (int it = 0; it < SA; ++it) r_act[it] = ld_narrow(b.actions + base * SA + lane + it * WAVE);
         if (b.actions_out) {  // VecTask.step's clamp, folded in: self.actions receives the clamped actions
 #pragma unroll
             for (int it = 0; it < SA; ++it) {
                 r_act[it] = clamp1(r_act[it], -p.clip_actions, p.clip_actions);
-                st_stream(b.actions_out + base * SA + lane + it * WAVE, r_act[it]);
+                st_narrow(b.actions_out + base * SA + lane + it * WAVE, r_act[it]);
             }
         }
 #pragma unroll
