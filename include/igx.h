@@ -219,6 +219,48 @@ int igx_quantile_finish(void *workspace, double *out, igx_stream_t stream);
 /* torch.quantile(x, q) (linear interpolation) of n doubles -> *out (device); NaN if any element is NaN, as torch */
 int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream);
 
+/* The same quantile over the shards of a multi-GPU job in two collectives instead of six
+ * (torch.quantile over all environments, ant_imitate.py:527-543).  Every rank histograms its shard over
+ * IGX_QUANTILE_WINDOW_BINS bins of a window of the key space that all ranks share (bin 0 = below the window,
+ * the last bin = above it; the window starts as the whole key space and, after every call, is centred on the
+ * value just found, so that on slowly drifting data one histogram is enough):
+ *   igx_quantile_window_begin;
+ *   repeat { igx_quantile_window_histogram; all-reduce(sum) of the IGX_QUANTILE_WINDOW_HIST_WORDS uint32 at
+ *            workspace + IGX_QUANTILE_WINDOW_HIST_OFFSET; igx_quantile_window_locate; read the 4 x int64
+ *            decision {status, count, bin, round} } while status == IGX_QW_REFINED   (the bin that holds
+ *            the wanted rank held more than `capacity` elements: the window shrank to that bin);
+ *   status IGX_QW_COLLECT (or IGX_QW_VALUE: the bin is one single value, count = 0):
+ *            igx_quantile_window_collect writes {local count, smallest key above the bin, the shard's keys in
+ *            the bin} into `slots` (count + 2 uint64); all-gather the slots of all ranks;
+ *            igx_quantile_window_finish sorts the gathered keys, picks the two order statistics, interpolates
+ *            as igx_quantile_finish does and re-centres the window;
+ *   status IGX_QW_GIVE_UP (more than IGX_QUANTILE_WINDOW_MAX_ROUNDS histograms): use the six-pass select.
+ * The result has the bits of igx_quantile_f64 over the concatenated shards.  n_total < 2^31.
+ * `reset_window` != 0 (or a workspace that igx_quantile_window_begin has not seen) starts from the whole
+ * key space; all ranks must pass the same value. */
+#define IGX_QUANTILE_WINDOW_BINS 16384
+#define IGX_QUANTILE_WINDOW_HIST_WORDS (IGX_QUANTILE_WINDOW_BINS + 32)  /* [BINS] = number of NaNs */
+#define IGX_QUANTILE_WINDOW_HIST_OFFSET 128
+#define IGX_QUANTILE_WINDOW_WORKSPACE_BYTES (IGX_QUANTILE_WINDOW_HIST_OFFSET + 4 * IGX_QUANTILE_WINDOW_HIST_WORDS)
+#define IGX_QUANTILE_WINDOW_MAX_CANDIDATES 4096
+#define IGX_QUANTILE_WINDOW_MAX_ROUNDS 12
+#define IGX_QUANTILE_WINDOW_MAX_RANKS 1024
+#define IGX_QW_COLLECT 0
+#define IGX_QW_REFINED 1
+#define IGX_QW_VALUE 2
+#define IGX_QW_GIVE_UP 4
+int igx_quantile_window_begin(void *workspace, double q, int64_t n_total, int32_t reset_window, igx_stream_t stream);
+int igx_quantile_window_histogram(const double *x, int64_t n, void *workspace, igx_stream_t stream);
+/* capacity: 1..IGX_QUANTILE_WINDOW_MAX_CANDIDATES (all ranks the same); decision: 4 x int64 on the device */
+int igx_quantile_window_locate(void *workspace, int32_t capacity, int64_t *decision, igx_stream_t stream);
+/* slots: num_slots uint64 on the device, num_slots >= 2 + the decision's count */
+int igx_quantile_window_collect(const double *x, int64_t n, const void *workspace, uint64_t *slots, int64_t num_slots,
+                                igx_stream_t stream);
+/* gathered: [num_ranks][num_slots] uint64, rank order; *out (device, may be NULL) receives the value, which
+ * also stays in the workspace; to hand it to igx_ant_imitate_finish pass out = (double *)quantile_workspace + 5 */
+int igx_quantile_window_finish(void *workspace, const uint64_t *gathered, int32_t num_ranks, int64_t num_slots,
+                               double *out, igx_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * HumanoidImitate (tasks/humanoid_imitate.py): 63-dof / 22-body humanoid.
  * post_physics_step (:634-643): progress / randomize += 1, flagged resets

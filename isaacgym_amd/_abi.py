@@ -252,6 +252,14 @@ def IGX_QUANTILE_HIST_OFFSET(p):
 
 
 IGX_QUANTILE_WORKSPACE_BYTES = IGX_QUANTILE_HIST_OFFSET(IGX_QUANTILE_PASSES)
+IGX_QUANTILE_WINDOW_BINS = 16384
+IGX_QUANTILE_WINDOW_HIST_WORDS = IGX_QUANTILE_WINDOW_BINS + 32
+IGX_QUANTILE_WINDOW_HIST_OFFSET = 128
+IGX_QUANTILE_WINDOW_WORKSPACE_BYTES = IGX_QUANTILE_WINDOW_HIST_OFFSET + 4 * IGX_QUANTILE_WINDOW_HIST_WORDS
+IGX_QUANTILE_WINDOW_MAX_CANDIDATES = 4096
+IGX_QUANTILE_WINDOW_MAX_ROUNDS = 12
+IGX_QUANTILE_WINDOW_MAX_RANKS = 1024
+IGX_QW_COLLECT, IGX_QW_REFINED, IGX_QW_VALUE, IGX_QW_GIVE_UP = 0, 1, 2, 4
 
 
 class EpisodeBuffers(_Struct):

@@ -190,6 +190,331 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(QuantileState *sta
     }
 }
 
+// ---- the same select in two collectives: histogram over a shared window of the key space ----------------
+//
+// Bin 0 holds the keys below the window, bins 1 .. WBINS - 2 are 2^shift keys wide starting at `lo`, bin
+// WBINS - 1 holds everything above.  The located bin is the one that contains rank[0] of the all-reduced
+// histogram; when it holds at most `capacity` keys the ranks exchange those keys and sort them, otherwise
+// the window shrinks to that bin (or moves to the part below / above it) and the shards are counted again.
+constexpr int WBINS = IGX_QUANTILE_WINDOW_BINS;
+constexpr unsigned WMAGIC = 0x51574e44u;
+constexpr unsigned WSHIFT_MAX = 50;  // (WBINS - 2) << 50 still fits 64 bits
+constexpr unsigned WNONE = 0xffffffffu;
+constexpr unsigned IGX_QW_BAD_GATHER = 5;
+
+struct WindowState {  // the first 128 bytes of the workspace
+    unsigned long long lo;
+    unsigned long long rank[2];
+    double weight;
+    unsigned long long n_total;
+    unsigned long long below;  // keys in the bins before the located one
+    double result;
+    unsigned shift, magic;
+    unsigned bin, count;       // the located bin and what it holds (all ranks together)
+    unsigned rounds, status;
+    unsigned nan, inside;      // some element was NaN; rank[1] lies in the located bin too
+    unsigned capacity, pad[9];
+};
+static_assert(sizeof(WindowState) == IGX_QUANTILE_WINDOW_HIST_OFFSET, "state header");
+static_assert(IGX_QUANTILE_WINDOW_MAX_CANDIDATES == 4096, "the finishing sort holds the candidates in LDS");
+
+__device__ __forceinline__ unsigned *window_hist(void *ws)
+{
+    return reinterpret_cast<unsigned *>(static_cast<char *>(ws) + IGX_QUANTILE_WINDOW_HIST_OFFSET);
+}
+
+__device__ __forceinline__ unsigned window_bin(unsigned long long k, unsigned long long lo, unsigned shift)
+{
+    if (k < lo) return 0u;
+    const unsigned long long d = (k - lo) >> shift;
+    return d >= (unsigned long long)(WBINS - 2) ? (unsigned)(WBINS - 1) : (unsigned)d + 1u;
+}
+
+// smallest shift (at most WSHIFT_MAX) whose window spans `span` keys
+__device__ __forceinline__ unsigned shift_for_span(unsigned long long span)
+{
+    unsigned s = 0;
+    while (s < WSHIFT_MAX && ((unsigned long long)(WBINS - 2) << s) < span) ++s;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void window_begin_kernel(WindowState *st, double q, unsigned long long n_total, int reset)
+{
+    unsigned *hist = window_hist(st);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < IGX_QUANTILE_WINDOW_HIST_WORDS; i += gridDim.x * 256) hist[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        WindowState s = *st;
+        if (reset || s.magic != WMAGIC || s.shift > WSHIFT_MAX) {
+            s.lo = 0;
+            s.shift = WSHIFT_MAX;
+        }
+        const double ranks = q * (double)(n_total - 1);
+        const long long below = (long long)ranks;
+        const long long above = (long long)ceil(ranks);
+        s.rank[0] = (unsigned long long)below;
+        s.rank[1] = (unsigned long long)above;
+        s.weight = ranks - (double)below;
+        s.n_total = n_total;
+        s.below = 0;
+        s.result = 0.0;
+        s.magic = WMAGIC;
+        s.bin = WNONE;
+        s.count = 0;
+        s.rounds = 0;
+        s.status = IGX_QW_REFINED;
+        s.nan = 0;
+        s.inside = 0;
+        s.capacity = 0;
+        for (int i = 0; i < 9; ++i) s.pad[i] = 0;
+        *st = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void window_hist_kernel(const double *__restrict__ x, int64_t n, WindowState *st)
+{
+    __shared__ unsigned s_hist[WBINS];  // 64 KB
+    for (int i = threadIdx.x; i < WBINS; i += 1024) s_hist[i] = 0;
+    const unsigned long long lo = st->lo;
+    const unsigned shift = st->shift;
+    __syncthreads();
+    unsigned nans = 0;
+    auto count = [&](double v) {
+        nans += v != v ? 1u : 0u;
+        atomicAdd(&s_hist[window_bin(key_of(v), lo, shift)], 1u);
+    };
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld_narrow(x + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) count(v[u]);
+    }
+    for (; i < n; i += stride) count(ld_narrow(x + i));
+    __syncthreads();
+    unsigned *hist = window_hist(st);
+    for (int b = threadIdx.x; b < WBINS; b += 1024) {
+        const unsigned c = s_hist[b];
+        if (c) atomicAdd(&hist[b], c);
+    }
+    if (nans) atomicAdd(&hist[WBINS], nans);
+}
+
+// one block of 1024 threads x 16 bins: which bin holds rank[0], and what to do about it
+__global__ __launch_bounds__(1024) void window_locate_kernel(WindowState *st, unsigned capacity, long long *decision)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_below;
+    __shared__ unsigned s_bin, s_count, s_status;
+    unsigned *hist = window_hist(st);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) {
+        s_bin = WNONE;
+        s_count = 0;
+        s_below = 0;
+    }
+    unsigned loc[16];
+    unsigned long long tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        loc[i] = hist[t * 16 + i];
+        tot += loc[i];
+    }
+    unsigned long long inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    unsigned long long run = inc - tot;
+    for (int i = 0; i < w; ++i) run += s_wave[i];
+    const unsigned long long r0 = st->rank[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (r0 >= run && r0 < run + loc[i]) {  // at most one (thread, i)
+            s_bin = (unsigned)(t * 16 + i);
+            s_count = loc[i];
+            s_below = run;
+        }
+        run += loc[i];
+    }
+    __syncthreads();
+    if (t == 0) {
+        WindowState s = *st;
+        const unsigned b = s_bin, c = s_count;
+        s.rounds += 1;
+        s.bin = b;
+        s.count = c;
+        s.below = s_below;
+        s.inside = (b != WNONE && s.rank[1] - s_below < (unsigned long long)c) ? 1u : 0u;
+        s.nan |= hist[WBINS] != 0 ? 1u : 0u;
+        s.capacity = capacity;
+        unsigned status;
+        const bool interior = b >= 1u && b <= (unsigned)(WBINS - 2);
+        if (b == WNONE) {
+            status = IGX_QW_GIVE_UP;  // the histogram does not hold n_total elements
+        } else if (c <= capacity) {
+            status = IGX_QW_COLLECT;
+        } else if (interior && s.shift == 0) {
+            status = IGX_QW_VALUE;    // more than `capacity` copies of one key
+        } else if (s.rounds >= IGX_QUANTILE_WINDOW_MAX_ROUNDS) {
+            status = IGX_QW_GIVE_UP;
+        } else {
+            status = IGX_QW_REFINED;
+            if (interior) {
+                s.lo = s.lo + ((unsigned long long)(b - 1u) << s.shift);
+                s.shift = s.shift > 13u ? s.shift - 13u : 0u;  // (WBINS - 2) << (shift - 13) >= 1 << shift
+            } else if (b == 0u) {
+                s.shift = shift_for_span(s.lo);
+                s.lo = 0;
+            } else {
+                s.lo = s.lo + ((unsigned long long)(WBINS - 2) << s.shift);
+                s.shift = shift_for_span(0ull - s.lo);
+            }
+        }
+        if (status == IGX_QW_GIVE_UP) s.magic = 0;  // the next call starts from the whole key space
+        s.status = status;
+        *st = s;
+        s_status = status;
+        decision[0] = (long long)status;
+        decision[1] = status == IGX_QW_COLLECT ? (long long)c : 0ll;
+        decision[2] = (long long)b;
+        decision[3] = (long long)s.rounds;
+    }
+    __syncthreads();
+    if (s_status == IGX_QW_REFINED) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hist[t * 16 + i] = 0;
+        if (t < IGX_QUANTILE_WINDOW_HIST_WORDS - WBINS) hist[WBINS + t] = 0;
+    }
+}
+
+__global__ void window_slots_init_kernel(unsigned long long *slots)
+{
+    if (threadIdx.x == 0) slots[0] = 0ull;
+    if (threadIdx.x == 1) slots[1] = ~0ull;
+}
+
+// slots = {number of this shard's keys in the located bin, smallest key of this shard above that bin, the keys}
+__global__ __launch_bounds__(256) void window_collect_kernel(const double *__restrict__ x, int64_t n, const WindowState *st,
+                                                             unsigned long long *slots, long long num_slots)
+{
+    const unsigned long long lo = st->lo;
+    const unsigned shift = st->shift, b0 = st->bin;
+    const bool emit = st->status == IGX_QW_COLLECT;
+    unsigned long long mn = ~0ull;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned long long k = key_of(ld_narrow(x + i));
+        const unsigned b = window_bin(k, lo, shift);
+        if (b == b0) {
+            if (emit) {
+                const unsigned long long pos = atomicAdd(&slots[0], 1ull);
+                if ((long long)pos + 2 < num_slots) slots[2 + pos] = k;
+            }
+        } else if (b > b0) {
+            mn = k < mn ? k : mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(mn, off);
+        mn = o < mn ? o : mn;
+    }
+    if ((threadIdx.x & 63) == 0 && mn != ~0ull) atomicMin(&slots[1], mn);
+}
+
+// one block: sort the gathered keys of the located bin, pick the two order statistics, interpolate like
+// quantile_finish_kernel, centre the window on the value for the next call
+__global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, const unsigned long long *__restrict__ g,
+                                                             int num_ranks, long long num_slots, double *out)
+{
+    __shared__ unsigned long long s_keys[IGX_QUANTILE_WINDOW_MAX_CANDIDATES];
+    __shared__ unsigned s_off[IGX_QUANTILE_WINDOW_MAX_RANKS + 1];
+    __shared__ unsigned long long s_min;
+    __shared__ unsigned s_ok;
+    const int t = threadIdx.x;
+    const WindowState s = *st;
+    if (t == 0) {
+        unsigned long long total = 0, mn = ~0ull;
+        bool ok = s.status == IGX_QW_COLLECT || s.status == IGX_QW_VALUE;
+        for (int r = 0; r < num_ranks; ++r) {
+            const unsigned long long c = g[(long long)r * num_slots];
+            const unsigned long long m = g[(long long)r * num_slots + 1];
+            s_off[r] = (unsigned)(total < IGX_QUANTILE_WINDOW_MAX_CANDIDATES ? total : IGX_QUANTILE_WINDOW_MAX_CANDIDATES);
+            if ((long long)c + 2 > num_slots) ok = false;
+            total += c;
+            mn = m < mn ? m : mn;
+        }
+        const unsigned long long want = s.status == IGX_QW_COLLECT ? s.count : 0ull;
+        if (total != want || total > IGX_QUANTILE_WINDOW_MAX_CANDIDATES) ok = false;
+        s_off[num_ranks] = ok ? (unsigned)total : 0u;
+        s_min = mn;
+        s_ok = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool ok = s_ok != 0;
+    const unsigned total = s_off[num_ranks];
+    unsigned P = 2;
+    while (P < total) P <<= 1;
+    for (unsigned i = t; i < P; i += 1024) s_keys[i] = ~0ull;
+    __syncthreads();
+    if (ok)
+        for (int r = 0; r < num_ranks; ++r) {
+            const unsigned o = s_off[r], c = s_off[r + 1] - o;
+            for (unsigned j = t; j < c; j += 1024) s_keys[o + j] = g[(long long)r * num_slots + 2 + j];
+        }
+    __syncthreads();
+    for (unsigned size = 2; size <= P; size <<= 1)
+        for (unsigned str = size >> 1; str > 0; str >>= 1) {
+            for (unsigned i = t; i < P / 2; i += 1024) {
+                const unsigned a = 2 * i - (i & (str - 1)), b = a + str;  // the pair this compare-exchange owns
+                const bool up = (a & size) == 0;
+                const unsigned long long ka = s_keys[a], kb = s_keys[b];
+                if ((ka > kb) == up) {
+                    s_keys[a] = kb;
+                    s_keys[b] = ka;
+                }
+            }
+            __syncthreads();
+        }
+    if (t == 0) {
+        WindowState n = s;
+        unsigned long long k0, k1;
+        if (s.status == IGX_QW_VALUE) {
+            k0 = s.lo + (unsigned long long)(s.bin - 1u);
+            k1 = (s.rank[1] == s.rank[0] || s.inside) ? k0 : s_min;
+        } else {
+            const unsigned long long i0 = s.rank[0] - s.below;
+            k0 = i0 < total ? s_keys[i0] : 0ull;
+            k1 = s.rank[1] == s.rank[0] ? k0 : (s.inside ? s_keys[i0 + 1 < total ? i0 + 1 : i0] : s_min);
+        }
+        const double a = value_of(k0), b = value_of(k1), w = s.weight;
+        const double diff = b - a;
+        double r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+        if (s.nan || !ok) r = __longlong_as_double(0x7ff8000000000000ll);
+        n.result = r;
+        n.rounds = 0;
+        if (!ok) {
+            n.status = IGX_QW_BAD_GATHER;
+            n.magic = 0;  // the next call starts from the whole key space
+        } else {
+            if (s.status == IGX_QW_COLLECT) {  // keep the located bin between capacity / 64 and capacity / 2 keys
+                if (s.count > s.capacity / 2u && n.shift > 0u) n.shift -= 1u;
+                else if (s.count < s.capacity / 64u && n.shift < WSHIFT_MAX) n.shift += 1u;
+            }
+            const unsigned long long half = (unsigned long long)(WBINS / 2 - 1) << n.shift;
+            n.lo = k0 > half ? k0 - half : 0ull;
+        }
+        *st = n;
+        if (out) *out = r;
+    }
+}
+
 static int check_ws(void *ws, const char *who)
 {
     if (!ws) return fail(IGX_E_NULL, "%s: workspace is NULL", who);
@@ -245,4 +570,82 @@ extern "C" int igx_quantile_f64(const double *x, int64_t n, double q, double *ou
         rc = igx_quantile_histogram(x, n, workspace, pass, stream);
     if (rc != IGX_OK) return rc;
     return igx_quantile_finish(workspace, out, stream);
+}
+
+extern "C" int igx_quantile_window_begin(void *workspace, double q, int64_t n_total, int32_t reset_window, igx_stream_t stream)
+{
+    int rc = check_ws(workspace, "igx_quantile_window_begin");
+    if (rc != IGX_OK) return rc;
+    if (!(q >= 0.0 && q <= 1.0)) return fail(IGX_E_PARAM, "igx_quantile_window_begin: q must lie in [0, 1]");
+    if (n_total <= 0 || n_total >= (int64_t(1) << 31))
+        return fail(IGX_E_SIZE, "igx_quantile_window_begin: n_total must lie in [1, 2^31)");
+    hipLaunchKernelGGL(window_begin_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<WindowState *>(workspace), q, (unsigned long long)n_total, (int)reset_window);
+    return launch_status("igx_quantile_window_begin");
+}
+
+extern "C" int igx_quantile_window_histogram(const double *x, int64_t n, void *workspace, igx_stream_t stream)
+{
+    int rc = check_ws(workspace, "igx_quantile_window_histogram");
+    if (rc != IGX_OK) return rc;
+    if (n < 0) return fail(IGX_E_SIZE, "igx_quantile_window_histogram: negative n");
+    if (n > 0 && !x) return fail(IGX_E_NULL, "igx_quantile_window_histogram: x is NULL");
+    static const int per_thread = tuning_int("IGX_QUANTILE_WINDOW_PER_THREAD", 16);
+    int64_t blocks = (n + 1024 * (int64_t)per_thread - 1) / (1024 * (int64_t)per_thread);
+    blocks = blocks < 1 ? 1 : blocks > 512 ? 512 : blocks;
+    hipLaunchKernelGGL(window_hist_kernel, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), x, n,
+                       static_cast<WindowState *>(workspace));
+    return launch_status("igx_quantile_window_histogram");
+}
+
+extern "C" int igx_quantile_window_locate(void *workspace, int32_t capacity, int64_t *decision, igx_stream_t stream)
+{
+    int rc = check_ws(workspace, "igx_quantile_window_locate");
+    if (rc != IGX_OK) return rc;
+    if (!decision) return fail(IGX_E_NULL, "igx_quantile_window_locate: decision is NULL");
+    if (capacity < 1 || capacity > IGX_QUANTILE_WINDOW_MAX_CANDIDATES)
+        return fail(IGX_E_PARAM, "igx_quantile_window_locate: capacity %d outside [1, %d]", capacity,
+                    IGX_QUANTILE_WINDOW_MAX_CANDIDATES);
+    hipLaunchKernelGGL(window_locate_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       static_cast<WindowState *>(workspace), (unsigned)capacity, reinterpret_cast<long long *>(decision));
+    return launch_status("igx_quantile_window_locate");
+}
+
+extern "C" int igx_quantile_window_collect(const double *x, int64_t n, const void *workspace, uint64_t *slots,
+                                           int64_t num_slots, igx_stream_t stream)
+{
+    int rc = check_ws(const_cast<void *>(workspace), "igx_quantile_window_collect");
+    if (rc != IGX_OK) return rc;
+    if (!slots) return fail(IGX_E_NULL, "igx_quantile_window_collect: slots is NULL");
+    if (num_slots < 2 || num_slots > IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2)
+        return fail(IGX_E_SIZE, "igx_quantile_window_collect: num_slots %lld outside [2, %d]", (long long)num_slots,
+                    IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2);
+    if (n < 0) return fail(IGX_E_SIZE, "igx_quantile_window_collect: negative n");
+    if (n > 0 && !x) return fail(IGX_E_NULL, "igx_quantile_window_collect: x is NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned long long *sl = reinterpret_cast<unsigned long long *>(slots);
+    hipLaunchKernelGGL(window_slots_init_kernel, dim3(1), dim3(64), 0, st, sl);
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(window_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n,
+                       static_cast<const WindowState *>(workspace), sl, (long long)num_slots);
+    return launch_status("igx_quantile_window_collect");
+}
+
+extern "C" int igx_quantile_window_finish(void *workspace, const uint64_t *gathered, int32_t num_ranks, int64_t num_slots,
+                                          double *out, igx_stream_t stream)
+{
+    int rc = check_ws(workspace, "igx_quantile_window_finish");
+    if (rc != IGX_OK) return rc;
+    if (!gathered) return fail(IGX_E_NULL, "igx_quantile_window_finish: gathered is NULL");
+    if (num_ranks < 1 || num_ranks > IGX_QUANTILE_WINDOW_MAX_RANKS)
+        return fail(IGX_E_PARAM, "igx_quantile_window_finish: num_ranks %d outside [1, %d]", num_ranks,
+                    IGX_QUANTILE_WINDOW_MAX_RANKS);
+    if (num_slots < 2 || num_slots > IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2)
+        return fail(IGX_E_SIZE, "igx_quantile_window_finish: num_slots %lld outside [2, %d]", (long long)num_slots,
+                    IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2);
+    hipLaunchKernelGGL(window_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       static_cast<WindowState *>(workspace), reinterpret_cast<const unsigned long long *>(gathered),
+                       (int)num_ranks, (long long)num_slots, out);
+    return launch_status("igx_quantile_window_finish");
 }

@@ -99,6 +99,20 @@ def all_gather_rows(rows, group=None):
     return out.to(dev)
 
 
+def all_reduce_sum(t, group=None):
+    """Sum an integer tensor over the ranks in place (counts of a histogram: the order of the additions cannot
+    change the bits).  Device tensors travel through the host under a host-only backend."""
+    if world_size(group) == 1:
+        return t
+    if t.device.type != "cpu" and _host_backend(group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def max_over_ranks(value, device, group=None):
     """MAX of a host scalar over the ranks (benchmark timing)."""
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)

@@ -470,3 +470,90 @@ def quantile_sharded(x, q, n_total, workspace, all_reduce):
             all_reduce(words[off:off + 2 * 2048])
         _lib.check(L.igx_quantile_finish(ws, None, st))
     return workspace.view(torch.float64)[5].clone()
+
+
+class WindowQuantile:
+    """torch.quantile over the shards of a multi-GPU job in two collectives: one all-reduce of a 16 384-bin
+    histogram over a window of the key space that all ranks share, one all-gather of the keys in the bin
+    that holds the wanted rank (igx_quantile_window_*).  The window follows the value from call to call;
+    a first call, or a value that left the window, costs further histogram rounds, and data the window
+    cannot resolve (IGX_QW_GIVE_UP) goes to the six-pass select of `quantile_sharded`.  The bits are those
+    of `quantile_f64` over the concatenated shards.  One object per (tensor stream, quantile): the window
+    is state."""
+
+    def __init__(self, device, capacity=_abi.IGX_QUANTILE_WINDOW_MAX_CANDIDATES):
+        if not 1 <= capacity <= _abi.IGX_QUANTILE_WINDOW_MAX_CANDIDATES:
+            raise ValueError("capacity outside [1, %d]" % _abi.IGX_QUANTILE_WINDOW_MAX_CANDIDATES)
+        self.device = torch.device(device)
+        self.capacity = int(capacity)
+        self.workspace = self._alloc(_abi.IGX_QUANTILE_WINDOW_WORKSPACE_BYTES // 4, torch.int32)
+        self.decision = self._alloc(4, torch.int64)
+        self.slots = self._alloc(_abi.IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2, torch.int64)
+        self.collectives = 0   # of the last run()
+        self.rounds = 0
+        self.fallbacks = 0     # runs that ended in the six-pass select
+
+    def _alloc(self, n, dtype):
+        return torch.zeros(n, dtype=dtype, device=self.device)
+
+    # -- the five kernels (tests replace these with the CPU restatement) --
+    def _call(self, name, *args):
+        with torch.cuda.device(self.device):
+            _lib.check(getattr(_lib.lib(), name)(*args, _lib.current_stream(self.device)))
+
+    def begin(self, q, n_total, reset):
+        self._call("igx_quantile_window_begin", _lib.tensor_ptr(self.workspace), C.c_double(q), C.c_int64(n_total),
+                   C.c_int32(1 if reset else 0))
+
+    def histogram(self, x):
+        self._call("igx_quantile_window_histogram", _lib.tensor_ptr(x, torch.float64), C.c_int64(x.numel()),
+                   _lib.tensor_ptr(self.workspace))
+
+    def locate(self):
+        self._call("igx_quantile_window_locate", _lib.tensor_ptr(self.workspace), C.c_int32(self.capacity),
+                   _lib.tensor_ptr(self.decision))
+
+    def collect(self, x, num_slots):
+        self._call("igx_quantile_window_collect", _lib.tensor_ptr(x, torch.float64), C.c_int64(x.numel()),
+                   _lib.tensor_ptr(self.workspace), _lib.tensor_ptr(self.slots), C.c_int64(num_slots))
+
+    def finish(self, gathered, num_ranks, num_slots, out):
+        self._call("igx_quantile_window_finish", _lib.tensor_ptr(self.workspace), _lib.tensor_ptr(gathered, torch.int64),
+                   C.c_int32(num_ranks), C.c_int64(num_slots), _lib.tensor_ptr(out, torch.float64) if out is not None else None)
+
+    # -- the protocol --
+    def hist_view(self):
+        off = _abi.IGX_QUANTILE_WINDOW_HIST_OFFSET // 4
+        return self.workspace[off:off + _abi.IGX_QUANTILE_WINDOW_HIST_WORDS]
+
+    def result(self):
+        """The value of the last run() (0-dim fp64 view of the workspace)."""
+        return self.workspace.view(torch.float64)[6]
+
+    def run(self, x, q, n_total, all_reduce, all_gather, out=None, reset=False):
+        """`all_reduce(t)` sums an int32 tensor over the ranks in place; `all_gather(t)` returns the [world, len(t)]
+        int64 tensor of every rank's `t` in rank order.  Returns True when the window protocol produced the value
+        (in `out` when given, and in result()), False when the caller has to run the six-pass select."""
+        if x.dtype != torch.float64 or not x.is_contiguous():
+            raise ValueError("x must be a contiguous fp64 tensor")
+        self.collectives = self.rounds = 0
+        self.begin(q, n_total, reset)
+        for _ in range(_abi.IGX_QUANTILE_WINDOW_MAX_ROUNDS + 1):
+            self.histogram(x)
+            all_reduce(self.hist_view())
+            self.collectives += 1
+            self.rounds += 1
+            self.locate()
+            status, count = (int(v) for v in self.decision[:2].tolist())  # synchronises
+            if status == _abi.IGX_QW_REFINED:
+                continue
+            if status in (_abi.IGX_QW_COLLECT, _abi.IGX_QW_VALUE):
+                num_slots = count + 2
+                self.collect(x, num_slots)
+                gathered = all_gather(self.slots[:num_slots]).contiguous()
+                self.collectives += 1
+                self.finish(gathered, gathered.shape[0], num_slots, out)
+                return True
+            break
+        self.fallbacks += 1
+        return False

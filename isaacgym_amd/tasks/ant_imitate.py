@@ -2,11 +2,13 @@
 Observations as Ant; the reward is exp(-|joint pose - target frame|_1) with a reset
 threshold at max(1.8, 0.99-quantile over ALL environments) (:447-555), evaluated in
 fp64 like the reference (its motion table comes from np.loadtxt).  One fused kernel, an
-exact device quantile (radix select; histograms all-reduced over the ranks of an
-environment-sharded job) and one finishing kernel per step."""
+exact device quantile and one finishing kernel per step.  In an environment-sharded job the quantile
+is the one exchange: by default two collectives per step (ops.WindowQuantile: a histogram over a window
+of the key space that follows the value, then the keys of one bin), or the six all-reduced histograms
+of the radix select (cfg env.quantileCollectives: "radix"), which is also where data goes that the
+window cannot resolve."""
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from .. import _abi, distributed, ops
 from .locomotion import Ant
@@ -30,6 +32,11 @@ class AntImitate(Ant):
         self._pose_diff = torch.zeros(self.num_envs, device=self.device, dtype=torch.float64)
         self._qws = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=self.device)
         self._group = process_group
+        self._n_total = None  # environments of all ranks (asked once)
+        self._window = None
+        self.quantile_collectives = self.cfg["env"].get("quantileCollectives", "window")
+        if self.quantile_collectives not in ("window", "radix"):
+            raise ValueError("env.quantileCollectives must be 'window' or 'radix'")
 
     def _imitate_args(self, n_total):
         return ops.imitate_args(self.motion_to_imitate, self.target_pose_idx, self._pose_diff, self._qws,
@@ -43,12 +50,24 @@ class AntImitate(Ant):
         if world == 1:
             ops.ant_imitate_step(self._params(), self._buffers(), self._imitate_args(self.num_envs), self.num_envs)
         else:
-            counts = distributed.gather_records(torch.tensor([self.num_envs], device=self.device), self._group)
-            im = self._imitate_args(int(counts.sum()))
+            if self._n_total is None:
+                counts = distributed.gather_records(torch.tensor([self.num_envs], device=self.device), self._group)
+                self._n_total = int(counts.sum())
+            im = self._imitate_args(self._n_total)
             p, b = self._params(), self._buffers()
             ops.ant_imitate_observe(p, b, im, self.num_envs)
-            ops.quantile_sharded(self._pose_diff, self.QUANTILE_THRESHOLD, im.n_total, self._qws,
-                                 lambda h: dist.all_reduce(h, group=self._group))
+            done = False
+            if self.quantile_collectives == "window" and self._n_total < (1 << 31):
+                if self._window is None:
+                    self._window = ops.WindowQuantile(self.device)
+                # the value goes where igx_ant_imitate_finish reads it: the result field of the select's workspace
+                done = self._window.run(self._pose_diff, self.QUANTILE_THRESHOLD, self._n_total,
+                                        lambda h: distributed.all_reduce_sum(h, self._group),
+                                        lambda t: distributed.gather_records(t, self._group),
+                                        out=self._qws.view(torch.float64)[5:6])
+            if not done:
+                ops.quantile_sharded(self._pose_diff, self.QUANTILE_THRESHOLD, self._n_total, self._qws,
+                                     lambda h: distributed.all_reduce_sum(h, self._group))
             ops.ant_imitate_finish(p, b, im, self.num_envs)
         self.extras["true_objective"] = self._true_objective
 

@@ -1790,6 +1790,182 @@ int orc_quantile_finish(void *ws, double *out)
     return 0;
 }
 
+/* The quantile in two collectives (igx_quantile_window_* of include/igx.h), restated serially: the shards are
+ * counted over the bins of a shared window of the key space, the all-reduced histogram names the bin that holds
+ * rank[0]; a bin of at most `capacity` keys is exchanged and sorted, a fuller one becomes the next window. */
+typedef struct {
+    uint64_t lo, rank[2];
+    double weight;
+    uint64_t n_total, below;
+    double result;
+    uint32_t shift, magic, bin, count, rounds, status, nan, inside, capacity, pad[9];
+} window_state;
+#define QW_MAGIC 0x51574e44u
+#define QW_SHIFT_MAX 50u
+#define QW_NONE 0xffffffffu
+#define QW_BAD_GATHER 5u
+#define QW_INTERIOR ((uint64_t)(IGX_QUANTILE_WINDOW_BINS - 2))
+
+static uint32_t *qw_hist(void *ws) { return (uint32_t *)((char *)ws + IGX_QUANTILE_WINDOW_HIST_OFFSET); }
+static uint32_t qw_bin(uint64_t k, uint64_t lo, uint32_t shift)
+{
+    if (k < lo) return 0;
+    uint64_t d = (k - lo) >> shift;
+    return d >= QW_INTERIOR ? (uint32_t)(IGX_QUANTILE_WINDOW_BINS - 1) : (uint32_t)d + 1;
+}
+static uint32_t qw_shift_for(uint64_t span)
+{
+    uint32_t s = 0;
+    while (s < QW_SHIFT_MAX && (QW_INTERIOR << s) < span) ++s;
+    return s;
+}
+
+int orc_quantile_window_begin(void *ws, double q, int64_t n_total, int32_t reset)
+{
+    window_state *st = (window_state *)ws, keep = *st;
+    memset(qw_hist(ws), 0, 4 * IGX_QUANTILE_WINDOW_HIST_WORDS);
+    memset(st, 0, sizeof *st);
+    int fresh = reset || keep.magic != QW_MAGIC || keep.shift > QW_SHIFT_MAX;
+    st->lo = fresh ? 0 : keep.lo;
+    st->shift = fresh ? QW_SHIFT_MAX : keep.shift;
+    double ranks = q * (double)(n_total - 1);
+    int64_t below = (int64_t)ranks;
+    st->rank[0] = (uint64_t)below;
+    st->rank[1] = (uint64_t)(int64_t)ceil(ranks);
+    st->weight = ranks - (double)below;
+    st->n_total = (uint64_t)n_total;
+    st->magic = QW_MAGIC;
+    st->bin = QW_NONE;
+    st->status = IGX_QW_REFINED;
+    return 0;
+}
+
+int orc_quantile_window_histogram(const double *x, int64_t n, void *ws)
+{
+    const window_state *st = (const window_state *)ws;
+    uint32_t *hist = qw_hist(ws);
+    for (int64_t i = 0; i < n; ++i) {
+        if (x[i] != x[i]) hist[IGX_QUANTILE_WINDOW_BINS] += 1;
+        hist[qw_bin(q_key(x[i]), st->lo, st->shift)] += 1;
+    }
+    return 0;
+}
+
+int orc_quantile_window_locate(void *ws, int32_t capacity, int64_t *decision)
+{
+    window_state *st = (window_state *)ws;
+    uint32_t *hist = qw_hist(ws);
+    uint64_t run = 0;
+    uint32_t bin = QW_NONE;
+    for (uint32_t b = 0; b < IGX_QUANTILE_WINDOW_BINS; ++b) {
+        if (st->rank[0] >= run && st->rank[0] < run + hist[b]) { bin = b; break; }
+        run += hist[b];
+    }
+    uint32_t count = bin == QW_NONE ? 0 : hist[bin];
+    st->rounds += 1;
+    st->bin = bin;
+    st->count = count;
+    st->below = bin == QW_NONE ? 0 : run;
+    st->inside = (bin != QW_NONE && st->rank[1] - st->below < count) ? 1 : 0;
+    st->nan |= hist[IGX_QUANTILE_WINDOW_BINS] != 0;
+    st->capacity = (uint32_t)capacity;
+    int interior = bin >= 1 && bin <= IGX_QUANTILE_WINDOW_BINS - 2;
+    if (bin == QW_NONE) st->status = IGX_QW_GIVE_UP;
+    else if (count <= (uint32_t)capacity) st->status = IGX_QW_COLLECT;
+    else if (interior && st->shift == 0) st->status = IGX_QW_VALUE;
+    else if (st->rounds >= IGX_QUANTILE_WINDOW_MAX_ROUNDS) st->status = IGX_QW_GIVE_UP;
+    else {
+        st->status = IGX_QW_REFINED;
+        if (interior) {                        /* the bin becomes the window */
+            st->lo += (uint64_t)(bin - 1) << st->shift;
+            st->shift = st->shift > 13 ? st->shift - 13 : 0;
+        } else if (bin == 0) {                 /* everything below the window */
+            st->shift = qw_shift_for(st->lo);
+            st->lo = 0;
+        } else {                               /* everything above it */
+            st->lo += QW_INTERIOR << st->shift;
+            st->shift = qw_shift_for(0 - st->lo);
+        }
+        memset(hist, 0, 4 * IGX_QUANTILE_WINDOW_HIST_WORDS);
+    }
+    if (st->status == IGX_QW_GIVE_UP) st->magic = 0;
+    decision[0] = st->status;
+    decision[1] = st->status == IGX_QW_COLLECT ? count : 0;
+    decision[2] = bin;
+    decision[3] = st->rounds;
+    return 0;
+}
+
+/* slots[0] = keys of this shard in the located bin, slots[1] = its smallest key above the bin, then the keys
+ * (in the order of x; the device writes them in any order - the exchange sorts them) */
+int orc_quantile_window_collect(const double *x, int64_t n, const void *ws, uint64_t *slots, int64_t num_slots)
+{
+    const window_state *st = (const window_state *)ws;
+    slots[0] = 0;
+    slots[1] = ~0ull;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t k = q_key(x[i]);
+        uint32_t b = qw_bin(k, st->lo, st->shift);
+        if (b == st->bin) {
+            if (st->status == IGX_QW_COLLECT) {
+                if ((int64_t)slots[0] + 2 < num_slots) slots[2 + slots[0]] = k;
+                slots[0] += 1;
+            }
+        } else if (b > st->bin && k < slots[1]) slots[1] = k;
+    }
+    return 0;
+}
+
+static int qw_cmp(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+int orc_quantile_window_finish(void *ws, const uint64_t *gathered, int32_t num_ranks, int64_t num_slots, double *out)
+{
+    window_state *st = (window_state *)ws;
+    uint64_t keys[IGX_QUANTILE_WINDOW_MAX_CANDIDATES], total = 0, above = ~0ull;
+    int ok = st->status == IGX_QW_COLLECT || st->status == IGX_QW_VALUE;
+    for (int r = 0; r < num_ranks; ++r) {
+        const uint64_t *g = gathered + (int64_t)r * num_slots;
+        if ((int64_t)g[0] + 2 > num_slots) ok = 0;
+        for (uint64_t j = 0; ok && j < g[0]; ++j)
+            if (total + j < IGX_QUANTILE_WINDOW_MAX_CANDIDATES) keys[total + j] = g[2 + j];
+        total += g[0];
+        if (g[1] < above) above = g[1];
+    }
+    if (total != (st->status == IGX_QW_COLLECT ? st->count : 0u) || total > IGX_QUANTILE_WINDOW_MAX_CANDIDATES) ok = 0;
+    uint64_t k0 = 0, k1 = 0;
+    if (ok && st->status == IGX_QW_VALUE) {
+        k0 = st->lo + (uint64_t)(st->bin - 1);
+        k1 = (st->rank[1] == st->rank[0] || st->inside) ? k0 : above;
+    } else if (ok) {
+        qsort(keys, (size_t)total, 8, qw_cmp);
+        uint64_t i0 = st->rank[0] - st->below;
+        k0 = keys[i0];
+        k1 = st->rank[1] == st->rank[0] ? k0 : (st->inside ? keys[i0 + 1] : above);
+    }
+    double a = q_value(k0), b = q_value(k1), w = st->weight, diff = b - a;
+    double r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+    if (st->nan || !ok) r = NAN;
+    st->result = r;
+    st->rounds = 0;
+    if (!ok) {
+        st->status = QW_BAD_GATHER;
+        st->magic = 0;
+    } else {
+        if (st->status == IGX_QW_COLLECT) {
+            if (st->count > st->capacity / 2 && st->shift > 0) st->shift -= 1;
+            else if (st->count < st->capacity / 64 && st->shift < QW_SHIFT_MAX) st->shift += 1;
+        }
+        uint64_t half = (uint64_t)(IGX_QUANTILE_WINDOW_BINS / 2 - 1) << st->shift;
+        st->lo = k0 > half ? k0 - half : 0;
+    }
+    if (out) *out = r;
+    return 0;
+}
+
 int orc_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n)
 {
     return loco_step(p, b, n, 0, im);

@@ -356,6 +356,41 @@ def quantile_finish(ws):
     return out.value
 
 
+# ---- the quantile in two collectives (igx_quantile_window_*) ----
+def window_workspace():
+    return np.zeros(_abi.IGX_QUANTILE_WINDOW_WORKSPACE_BYTES // 4, np.int32)
+
+
+def window_begin(ws, q, n_total, reset=False):
+    assert lib().orc_quantile_window_begin(C.c_void_p(ws.ctypes.data), C.c_double(q), C.c_int64(n_total), C.c_int32(int(reset))) == 0
+
+
+def window_histogram(x, ws):
+    x = np.ascontiguousarray(x, np.float64)
+    assert lib().orc_quantile_window_histogram(C.c_void_p(x.ctypes.data), C.c_int64(x.size), C.c_void_p(ws.ctypes.data)) == 0
+
+
+def window_locate(ws, capacity, decision):
+    assert decision.dtype == np.int64 and decision.size >= 4
+    assert lib().orc_quantile_window_locate(C.c_void_p(ws.ctypes.data), C.c_int32(capacity), C.c_void_p(decision.ctypes.data)) == 0
+
+
+def window_collect(x, ws, slots, num_slots):
+    x = np.ascontiguousarray(x, np.float64)
+    assert slots.itemsize == 8 and slots.size >= num_slots
+    assert lib().orc_quantile_window_collect(C.c_void_p(x.ctypes.data), C.c_int64(x.size), C.c_void_p(ws.ctypes.data),
+                                             C.c_void_p(slots.ctypes.data), C.c_int64(num_slots)) == 0
+
+
+def window_finish(ws, gathered, num_ranks, num_slots):
+    gathered = np.ascontiguousarray(gathered)
+    assert gathered.itemsize == 8 and gathered.size >= num_ranks * num_slots
+    out = C.c_double(0.0)
+    assert lib().orc_quantile_window_finish(C.c_void_p(ws.ctypes.data), C.c_void_p(gathered.ctypes.data), C.c_int32(num_ranks),
+                                            C.c_int64(num_slots), C.byref(out)) == 0
+    return out.value
+
+
 def imitate_args(arrays, num_frames, quantile, distance_floor, death_cost, n_total):
     """igx_imitate_args over numpy arrays: motion [F,8] f64, target_pose_idx [n] i64, pose_diff [n] f64."""
     im = _abi.ImitateArgs(num_frames=num_frames, quantile=quantile, distance_floor=distance_floor,

@@ -613,3 +613,79 @@ def observer_replay(g, observer, stats_step, to_tensor, to_np, sum_rtol=0.0):
         for (tag, v, s), (_, rv, rs) in zip(algo.writer.rows, ref_rows):
             assert s == rs, tag
             assert v == rv or abs(v - rv) <= 1e-6 * max(1.0, abs(rv)), (tag, v, rv)  # float32 means of the same values
+
+
+def oracle_window_quantile(capacity=4096):
+    """ops.WindowQuantile with its five kernels replaced by the CPU restatement (host tensors): the protocol
+    code under test is the product's, the arithmetic the checker's."""
+    import torch
+    from isaacgym_amd import ops
+    from oracle import oracle
+
+    class OracleWindowQuantile(ops.WindowQuantile):
+        def _alloc(self, n, dtype):
+            return torch.zeros(n, dtype=dtype)
+
+        def begin(self, q, n_total, reset):
+            oracle.window_begin(self.workspace.numpy(), q, n_total, reset)
+
+        def histogram(self, x):
+            oracle.window_histogram(x.numpy(), self.workspace.numpy())
+
+        def locate(self):
+            oracle.window_locate(self.workspace.numpy(), self.capacity, self.decision.numpy())
+
+        def collect(self, x, num_slots):
+            oracle.window_collect(x.numpy(), self.workspace.numpy(), self.slots.numpy(), num_slots)
+
+        def finish(self, gathered, num_ranks, num_slots, out):
+            v = oracle.window_finish(self.workspace.numpy(), gathered.numpy(), num_ranks, num_slots)
+            if out is not None:
+                out.fill_(v)
+
+    return OracleWindowQuantile("cpu", capacity)
+
+
+class LocalShards:
+    """The collectives of a sharded job run inside one process: the shards' objects take turns, `all_reduce` sums
+    the tensors the shards handed in, `all_gather` stacks them.  Drives N WindowQuantile objects in lock step."""
+
+    def __init__(self, objs):
+        self.objs = objs
+
+    def run(self, shards, q, reset=False, outs=None):
+        import threading
+        import torch
+        n_total = sum(int(s.numel()) for s in shards)
+        world = len(self.objs)
+        barrier = threading.Barrier(world)
+        box, res, err = [None] * world, [None] * world, []
+
+        def exchange(rank, t, combine):
+            box[rank] = t
+            barrier.wait()
+            out = combine([b for b in box])
+            barrier.wait()
+            return out
+
+        def work(rank):
+            try:
+                def all_reduce(t):
+                    t.copy_(exchange(rank, t.clone(), lambda ts: torch.stack(ts).sum(0).to(t.dtype)))
+
+                def all_gather(t):
+                    return exchange(rank, t.clone(), lambda ts: torch.stack(ts))
+                res[rank] = self.objs[rank].run(shards[rank], q, n_total, all_reduce, all_gather,
+                                                out=None if outs is None else outs[rank], reset=reset)
+            except BaseException as e:  # noqa: BLE001 - re-raised in the caller
+                err.append(e)
+                barrier.abort()
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            raise err[0]
+        return res

@@ -86,7 +86,65 @@ def quantile():
     return got
 
 
-out = {"allegro": hands("allegro"), "shadow": hands("shadow"), "quantile": quantile()}
+def window_quantile():
+    """The two-collective protocol on the product's kernels; every step against torch.quantile and the six-pass select."""
+    n = 400003
+    s, c = distributed.env_shard(n, rank, world)
+    wq = ops.WindowQuantile(DEV)
+    ws = torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+    gen = torch.Generator().manual_seed(6)
+    counts = []
+    for step in range(6):
+        x = torch.randn(n, dtype=torch.float64, generator=gen).abs() * (1.0 + 0.01 * step)
+        if step == 4:
+            x[::2] = 1.25  # far more copies of one value than the exchange carries
+        mine = x[s:s + c].to(DEV).contiguous()
+        q = 0.5 if step >= 3 else 0.99
+        ok = wq.run(mine, q, n, distributed.all_reduce_sum, distributed.gather_records, out=ws.view(torch.float64)[5:6])
+        want = float(torch.quantile(x, q))
+        assert ok and float(wq.result()) == want == float(ws.view(torch.float64)[5]), (step, float(wq.result()), want)
+        assert float(ops.quantile_sharded(mine, q, n, ws, distributed.all_reduce_sum)) == want
+        counts.append(wq.collectives)
+    assert counts[1] == counts[2] == 2 and counts[4] > 2, counts
+    return counts
+
+
+def ant_imitate_class(protocol):
+    """The AntImitate class on the reference's recording, each rank with its half of the environments: the
+    global threshold, flags and target frames are those of the unsharded recording."""
+    from isaacgym_amd import cfg as C, tasks
+    from isaacgym_amd.sim import ReplaySim
+    from tests import helpers as H
+    g = H.load_golden("ant_imitate")
+    N, T = g["meta"]["N"], g["meta"]["T"]
+    s, c = distributed.env_shard(N, rank, world)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    cut = lambda a: a[s:s + c]
+    dofs = lambda a: np.ascontiguousarray(a.reshape(N, 8, 2)[s:s + c])
+    frames = [dict(root_states=cut(g["in_root"][t]), dof_state=dofs(g["in_dof_state"][t]).reshape(c * 8, 2),
+                   sensors=cut(g["in_sensors"][t])) for t in range(T)]
+    init = dict(root_states=cut(g["in_root"][0]), dof_state=dofs(g["in_dof_state"][0]), sensors=cut(g["in_sensors"][0]))
+    sim = ReplaySim(c, DEV, init, frames, dict(dof_limits_lower=g["dof_limits_lower"].tolist(),
+                                               dof_limits_upper=g["dof_limits_upper"].tolist()))
+    task = tasks.AntImitate(C.task_config("AntImitate", c, quantileCollectives=protocol), DEV, DEV, sim=sim, motion=g["motion"])
+    task.initial_root_states.copy_(dev(cut(g["initial_root_states"])))
+    task.initial_dof_pos.copy_(dev(cut(g["initial_dof_pos"])))
+    task.progress_buf.copy_(dev(cut(g["progress0"])))
+    task.potentials.copy_(dev(cut(g["potentials0"])))
+    for t in range(T):
+        task.reset_buf.copy_(dev(cut(g["in_reset"][t])))
+        task.reset_rand = dev(cut(g["rand"][t]))
+        _, rew, reset, _ = task.step(dev(cut(g["in_actions"][t])))
+        assert task.pose_threshold == float(g["threshold"][t]), (protocol, t, task.pose_threshold, float(g["threshold"][t]))
+        assert np.array_equal(reset.cpu().numpy(), cut(g["reset"][t]))
+        assert np.array_equal(task.progress_buf.cpu().numpy(), cut(g["progress"][t]))
+        assert np.array_equal(task.target_pose_idx.cpu().numpy(), cut(g["target_pose_idx"][t]))
+    if protocol == "window":
+        assert task._window is not None and task._window.fallbacks == 0
+    return T
+
+
+out = {"ant_imitate": [ant_imitate_class("window"), ant_imitate_class("radix")], "allegro": hands("allegro"), "shadow": hands("shadow"), "quantile": quantile(), "window_quantile": window_quantile()}
 dist.barrier()
 if rank == 0:
     print(json.dumps(out))

@@ -208,6 +208,52 @@ def test_quantile_sharded_over_two_gloo_ranks_equals_torch(tmp_path):
         assert np.array_equal(got, want), (r, got, want)
 
 
+def _window_rank(rank, world, port, n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    from tests.helpers import oracle_window_quantile
+    wq = oracle_window_quantile()
+    start, count = distributed.env_shard(n, rank, world)
+    rng = np.random.default_rng(12)
+    rows = []
+    for step in range(12):
+        x = np.abs(rng.standard_normal(n)) * (1.0 + 0.02 * step)
+        if step == 7:
+            x[: n // 2] = 0.75  # more copies of one value than the exchange can carry
+        if step == 9:
+            x *= 1e5            # the value leaves the window
+        ok = wq.run(torch.from_numpy(x[start:start + count].copy()), 0.5, n,
+                    lambda t: distributed.all_reduce_sum(t), lambda t: distributed.gather_records(t))
+        rows.append([float(wq.result()), float(ok), float(wq.collectives)])
+    np.save(os.path.join(outdir, "w%d.npy" % rank), np.array(rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_quantile_over_two_gloo_ranks_equals_torch_in_two_collectives(tmp_path):
+    """The two-collective form of the same exchange: the product's protocol (ops.WindowQuantile.run) with real
+    gloo collectives over two processes; values bit-equal torch.quantile over all environments, and once the
+    window sits on the value a call costs one all-reduce and one all-gather."""
+    n, world = 60001, 2
+    mp.spawn(_window_rank, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(12)
+    want = []
+    for step in range(12):
+        x = np.abs(rng.standard_normal(n)) * (1.0 + 0.02 * step)
+        if step == 7:
+            x[: n // 2] = 0.75
+        if step == 9:
+            x *= 1e5
+        want.append(float(torch.quantile(torch.from_numpy(x), 0.5)))
+    got = [np.load(os.path.join(str(tmp_path), "w%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(got[0], got[1])
+    assert np.array_equal(got[0][:, 0], np.array(want))
+    assert np.all(got[0][:, 1] == 1.0)
+    assert list(got[0][[2, 3, 4, 5, 6, 11], 2]) == [2.0] * 6, got[0][:, 2]
+    assert got[0][7, 2] > 2, got[0][:, 2]  # shrinking the window down to the one repeated value
+
+
 def _queued_rank(rank, world, port, n, outdir, which):
     """The same sharded run twice: the record exchange on every step, and queued (distributed.ShardRecordQueue:
     one gather per `interval` steps, applied in step order) - consecutive_successes must come out bit-identical."""

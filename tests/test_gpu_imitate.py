@@ -148,3 +148,87 @@ def test_quantile_with_a_nan_is_nan_like_torch(n):
         assert torch.isnan(ops.quantile_f64(x.to(DEV), 0.99))
     x = torch.randn(n, generator=g, dtype=torch.float64)
     assert float(ops.quantile_f64(x.to(DEV), 0.99)) == float(torch.quantile(x, 0.99))  # the same workspace logic without NaN
+
+
+# ---- the quantile in two collectives (igx_quantile_window_*) -----------------------------------------------
+def _window_pair(world, capacity=4096):
+    return ([ops.WindowQuantile(DEV, capacity) for _ in range(world)],
+            [H.oracle_window_quantile(capacity) for _ in range(world)])
+
+
+def _window_step(devs, cpus, x, q, cuts, reset=False):
+    """One call of the protocol on `world` shards: the product's kernels and the CPU restatement in lock step;
+    the states they leave (window, located bin, counts, value) must be the same bytes."""
+    parts = [torch.from_numpy(np.ascontiguousarray(p)) for p in np.split(x, cuts)]
+    ok_d = H.LocalShards(devs).run([p.to(DEV) for p in parts], q, reset=reset)
+    ok_c = H.LocalShards(cpus).run(parts, q, reset=reset)
+    torch.cuda.synchronize()
+    assert ok_d == ok_c
+    state = _abi.IGX_QUANTILE_WINDOW_HIST_OFFSET // 4
+    for d, c in zip(devs, cpus):
+        assert d.workspace[:state].cpu().numpy().tobytes() == c.workspace[:state].numpy().tobytes()
+        assert (d.collectives, d.rounds) == (c.collectives, c.rounds)
+    return float(devs[0].result())
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_window_quantile_kernels_match_the_cpu_restatement_and_torch(world):
+    rng = np.random.default_rng(40 + world)
+    cases = {
+        "normal": lambda n: rng.standard_normal(n),
+        "narrow": lambda n: 1.0 + 1e-9 * rng.random(n),
+        "wide": lambda n: np.exp(40.0 * rng.standard_normal(n)) * rng.choice([-1.0, 1.0], n),
+        "ties": lambda n: rng.integers(0, 5, n).astype(np.float64),
+        "constant": lambda n: np.full(n, 2.5),
+        "inf": lambda n: np.where(rng.random(n) < 0.3, np.inf, rng.standard_normal(n)),
+    }
+    for name, make in cases.items():
+        for n in (1, 5, 1000, 70001):
+            x = make(n)
+            cuts = np.sort(rng.integers(0, n + 1, world - 1))
+            devs, cpus = _window_pair(world)
+            for q in (0.99, 0.5, 0.0, 1.0, float(rng.random())):
+                got, want = _window_step(devs, cpus, x, q, cuts), float(torch.quantile(torch.from_numpy(x), q))
+                assert got == want or (np.isnan(got) and np.isnan(want)), (name, n, q)  # inf - inf inside the lerp
+
+
+def test_window_quantile_small_capacity_and_nan():
+    rng = np.random.default_rng(44)
+    x = np.concatenate([np.full(5000, 3.0), rng.standard_normal(3000)])
+    rng.shuffle(x)
+    devs, cpus = _window_pair(2, capacity=16)
+    for q in (0.2, 0.5, 0.9):
+        assert _window_step(devs, cpus, x, q, [3001]) == float(torch.quantile(torch.from_numpy(x), q))
+    x[77] = np.nan
+    devs, cpus = _window_pair(2)
+    assert np.isnan(_window_step(devs, cpus, x, 0.5, [4000]))
+
+
+def test_window_quantile_at_a_million_per_shard_follows_the_value_in_two_collectives():
+    world, n = 2, 1 << 21
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    devs = [ops.WindowQuantile(DEV) for _ in range(world)]
+    ws = _ws()
+    counts = []
+    for step in range(5):
+        x = torch.randn(n, generator=gen, device=DEV, dtype=torch.float64).abs() * (1.0 + 0.01 * step)
+        shards = [x[: n // 2].contiguous(), x[n // 2:].contiguous()]
+        assert all(H.LocalShards(devs).run(shards, 0.99))
+        want = float(ops.quantile_f64(x, 0.99, ws))
+        assert float(devs[0].result()) == float(devs[1].result()) == want == float(torch.quantile(x.cpu(), 0.99))
+        counts.append(devs[0].collectives)
+    assert all(c == 2 for c in counts[1:]), counts
+
+
+def test_window_quantile_rejects_bad_arguments():
+    wq = ops.WindowQuantile(DEV)
+    with pytest.raises(RuntimeError, match="n_total"):
+        wq.begin(0.5, 1 << 31, False)
+    with pytest.raises(RuntimeError, match="q must lie"):
+        wq.begin(1.5, 10, False)
+    with pytest.raises(ValueError, match="capacity"):
+        ops.WindowQuantile(DEV, capacity=5000)
+    with pytest.raises(RuntimeError, match="num_slots"):
+        wq.collect(torch.zeros(4, dtype=torch.float64, device=DEV), 1)
+    with pytest.raises(ValueError, match="fp64"):
+        wq.run(torch.zeros(4, device=DEV), 0.5, 4, lambda t: None, lambda t: t.unsqueeze(0))

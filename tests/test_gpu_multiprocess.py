@@ -16,4 +16,4 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_calls():
     rc, out = launch.spawn_ranks([sys.executable, "-u", os.path.join(HERE, "shard_child.py")], 2, timeout=110)
     assert rc == 0, out
     d = json.loads(out.strip().splitlines()[-1])
-    assert set(d) == {"allegro", "shadow", "quantile"}
+    assert set(d) == {"allegro", "shadow", "quantile", "window_quantile", "ant_imitate"}

@@ -102,6 +102,21 @@ def main():
         report("ant_imitate_step(total)", timed(lambda i: ops.ant_imitate_step(p, sets[i % 3], im, n), a.steps), 556 + 32)
         report("ant_imitate_observe", timed(lambda i: ops.ant_imitate_observe(p, sets[i % 3], im, n), a.steps), 556 + 24)
         report("quantile_f64", timed(lambda i: ops.quantile_f64(pd, 0.99, ws), a.steps), 8 * 6)
+        # the two-collective form on one rank (identity collectives): kernels alone, and the whole protocol with
+        # the host's read of the decision between the all-reduce and the gather
+        wq = ops.WindowQuantile(DEV)
+        one = lambda t: t.unsqueeze(0)
+        wq.run(pd, 0.99, n, lambda t: t, one)
+
+        def window_kernels(i):
+            wq.begin(0.99, n, False)
+            wq.histogram(pd)
+            wq.locate()
+            wq.collect(pd, 4098)
+            wq.finish(wq.slots, 1, 4098, None)
+        report("quantile_window(kernels)", timed(window_kernels, a.steps), 8 * 2)
+        report("quantile_window(protocol)", timed(lambda i: wq.run(pd, 0.99, n, lambda t: t, one), a.steps), 8 * 2)
+        assert float(wq.result()) == float(ops.quantile_f64(pd, 0.99, ws)), "window quantile differs"
         del sets
     if on("math"):
         # torch_jit_utils kernels on 2^22 rows (inputs rotate over three sets so that no call re-reads cached lines);
