@@ -206,8 +206,9 @@ def main():
     ev0.record()
     run(args.warmup, args.steps, timed=True)
     ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps; the MAX over the ranks is taken below
     barrier()
-    elapsed = time.perf_counter() - t0
     if step_events:  # the episode kernels sit between ev0 and ev1: price the step kernel by its own pairs
         kernel_ms = sum(a.elapsed_time(b) for a, b in step_events) / len(step_events)
     else:
