@@ -137,6 +137,28 @@ def launch_ranks(args):
     return rc
 
 
+def init_group(dist, torch, backend, dev):
+    """Join the job's process group.  The collectives of this benchmark are a barrier and one MAX of a scalar, so
+    when RCCL cannot come up on this node (it raises on every rank alike) the ranks meet again over gloo on the
+    next port instead of losing the measurement; the JSON line names the backend that was used."""
+    if backend == "nccl":
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+            return "nccl"
+        except Exception as e:  # noqa: BLE001 - any failure of the RCCL bring-up
+            print("bench: RCCL bring-up failed (%s: %s); using gloo for the barrier" % (type(e).__name__, e),
+                  file=sys.stderr, flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    dist.init_process_group("gloo")
+    return "gloo"
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -153,11 +175,9 @@ def main():
     dev_index = local_rank if args.all_ranks_on_device < 0 else args.all_ranks_on_device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = args.backend
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        backend = init_group(dist, torch, args.backend, dev)
 
     spec = synthetic.ANT if args.task == "ant" else synthetic.HUMANOID
     step = ops.ant_step if args.task == "ant" else ops.humanoid_step
@@ -215,7 +235,7 @@ def main():
         kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per launch on the launch stream
 
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -234,7 +254,8 @@ def main():
             "config": {"workload": "%s obs/reward/reset fused post_physics_step, %d envs per GPU, AoS reference "
                                    "layout, in-kernel Philox resets" % (args.task, n),
                        "envs_per_gpu": n, "global_envs": n * world, "input_sets": NUM_INPUT_SETS,
-                       "parallelism": "env-shard x%d (no data-path collective)" % world},
+                       "parallelism": "env-shard x%d (no data-path collective)" % world,
+                       "collective_backend": backend if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": load_traffic() if args.task == "ant" and n == ENVS_PER_GPU else None,
