@@ -15,7 +15,8 @@ reference's task objects keeps working.  What differs:
   clamped observation copy of `step` are HIP kernels (igx_action_stage_step /
   igx_clamp, igx_vec_task_tail_step) writing into persistent tensors: the
   returned observation tensor is overwritten by the next `step` / `reset` call,
-  where the reference returns a fresh tensor.  The per-call noise draw is made
+  where the reference returns a fresh tensor (cfg env.freshStepOutputs: true
+  makes step() return copies instead).  The per-call noise draw is made
   inside the kernels (Philox), not by torch.randn_like.
 """
 import numpy as np
@@ -62,6 +63,9 @@ class VecTask:
         self.control_freq_inv = env.get("controlFrequencyInv", 1)
         self.clip_obs = env.get("clipObservations", np.inf)
         self.clip_actions = env.get("clipActions", np.inf)
+        # freshStepOutputs: step() hands back copies (as the reference's fresh tensors) instead of the persistent
+        # buffers that the next step overwrites - for callers that keep observations across steps
+        self.fresh_step_outputs = bool(config["env"].get("freshStepOutputs", False))
         self.total_train_env_frames = 0
         self.control_steps = 0
         self.dt = config["sim"]["dt"]
@@ -305,6 +309,14 @@ class VecTask:
                               self._states_out if self.num_states > 0 else None,
                               obs_noised=self.obs_buf if stage else None, cache=self._call_cache, **stage)
         self.timeout_buf = self._time_outs
+        if self.fresh_step_outputs:
+            dev = self.rl_device
+            fresh = (lambda t: t.clone()) if self._rl_same else (lambda t: t.to(dev))
+            self.extras["time_outs"] = fresh(self.timeout_buf)
+            obs = {"obs": fresh(self._obs_out)}
+            if self.num_states > 0:
+                obs["states"] = fresh(self._states_out)
+            return obs, fresh(self.rew_buf), fresh(self.reset_buf), self.extras
         if self._rl_same:
             self.extras["time_outs"] = self.timeout_buf
             self.obs_dict["obs"] = self._obs_out

@@ -591,3 +591,22 @@ def test_sharded_hand_keeps_collectives_off_the_task_stream(name, nact, monkeypa
     torch.cuda.synchronize()
     assert torch.equal(queued.consecutive_successes.view(torch.int32), direct.consecutive_successes.view(torch.int32))
     assert float(direct.consecutive_successes) != 0.0
+
+
+@pytest.mark.parametrize("name", ["Ant", "AllegroHand"])
+def test_fresh_step_outputs_do_not_alias_the_next_step(name):
+    """env.freshStepOutputs: what step() returned stays what it was after the next step (the default hands out
+    the persistent buffers, which the next step overwrites)."""
+    n = 2048
+    fresh = tasks.make(name, n, DEV, seed=9, freshStepOutputs=True)
+    plain = tasks.make(name, n, DEV, seed=9)
+    act = torch.rand(n, fresh.num_actions, device=DEV) * 2 - 1
+    o1, r1, d1, _ = fresh.step(act)
+    p1 = plain.step(act)
+    keep = (o1["obs"].clone(), r1.clone(), d1.clone())
+    assert torch.equal(o1["obs"], p1[0]["obs"]) and torch.equal(r1, p1[1]) and torch.equal(d1, p1[2])
+    o2, r2, d2, _ = fresh.step(-act)
+    p2 = plain.step(-act)
+    assert torch.equal(o1["obs"], keep[0]) and torch.equal(r1, keep[1]) and torch.equal(d1, keep[2])
+    assert o2["obs"].data_ptr() != o1["obs"].data_ptr() and not torch.equal(o2["obs"], o1["obs"])
+    assert torch.equal(o2["obs"], p2[0]["obs"]) and p2[0]["obs"].data_ptr() == p1[0]["obs"].data_ptr()
