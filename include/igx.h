@@ -208,7 +208,9 @@ int igx_ant_imitate_step(const igx_loco_params *p, const igx_loco_buffers *b, co
  * igx_quantile_begin zeroes the histograms and sets the two ranks from q and n_total; the
  * histogram kernel of pass p first picks the bins of pass p - 1 from its (all-reduced) histogram;
  * igx_quantile_finish picks the last digit and interpolates: the value goes to the workspace
- * (where igx_ant_imitate_finish reads it) and to *out unless out is NULL. */
+ * (where igx_ant_imitate_finish reads it) and to *out unless out is NULL.
+ * The optional tail outputs of igx_loco_buffers: obs_clamped is written by the observe call, time_outs by
+ * the finish call (it depends on the reset flags the threshold sets). */
 int igx_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,
                             int64_t n_envs, igx_stream_t stream);
 int igx_ant_imitate_finish(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im,

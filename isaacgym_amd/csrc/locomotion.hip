@@ -377,7 +377,7 @@ __device__ __forceinline__ void loco_tile(const igx_loco_params &p, const igx_lo
 
     // ---- drain: finished rows out as whole lines
     drain_rows<NOBS, TILE>(b.obs + base * NOBS, s_tile, nvalid, lane);
-    if (!IMIT && b.obs_clamped)  // the copy VecTask.step hands to the learner
+    if (b.obs_clamped)  // the copy VecTask.step hands to the learner
         drain_rows_clamped<NOBS, TILE>(b.obs_clamped + base * NOBS, s_tile, nvalid, lane, p.clip_obs);
     wave_sync();
     // up / heading vectors: transpose through the tile's first 384 floats
@@ -554,7 +554,8 @@ static int launch_loco(const igx_loco_params *p, const igx_loco_buffers *b, int6
 }
 
 // tasks/ant_imitate.py:523-555: the decisions that need the global threshold
-__global__ __launch_bounds__(256) void imitate_finish_kernel(const igx_loco_buffers b, const igx_imitate_args im, int64_t n)
+__global__ __launch_bounds__(256) void imitate_finish_kernel(const igx_loco_buffers b, const igx_imitate_args im, int64_t n,
+                                                             float max_episode_length_m1)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -575,6 +576,10 @@ __global__ __launch_bounds__(256) void imitate_finish_kernel(const igx_loco_buff
         idx = 0;
     }
     if (far || finished) im.target_pose_idx[e] = idx;
+    if (b.time_outs) {  // VecTask.step's time-out flag, on the reset flag as this kernel leaves it
+        const int64_t rst = far ? 1 : b.reset[e];
+        b.time_outs[e] = ((float)b.progress[e] >= max_episode_length_m1 && rst != 0) ? 1 : 0;
+    }
 }
 
 static int check_imitate(const igx_imitate_args *im, int64_t n, const char *who)
@@ -609,8 +614,9 @@ extern "C" int igx_ant_imitate_finish(const igx_loco_params *p, const igx_loco_b
     int rc = igx::check_imitate(im, n_envs, "igx_ant_imitate_finish");
     if (rc != IGX_OK || n_envs == 0) return rc;
     if (!b->reset || !b->rew) return igx::fail(IGX_E_NULL, "igx_ant_imitate_finish: reset / rew is NULL");
+    if (b->time_outs && !b->progress) return igx::fail(IGX_E_NULL, "igx_ant_imitate_finish: time_outs needs progress");
     hipLaunchKernelGGL(igx::imitate_finish_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), *b, *im, n_envs);
+                       static_cast<hipStream_t>(stream), *b, *im, n_envs, p->max_episode_length_m1);
     return igx::launch_status("igx_ant_imitate_finish");
 }
 

@@ -190,6 +190,124 @@ __global__ __launch_bounds__(256) void quantile_finish_kernel(QuantileState *sta
     }
 }
 
+// ascending bitonic sort of P (a power of two, <= 4096) keys in LDS by one block of 1024 threads;
+// the keys must be in place (barrier before the call); ends with a barrier
+__device__ __forceinline__ void bitonic_sort_1024(unsigned long long *s_keys, unsigned P)
+{
+    const unsigned t = threadIdx.x;
+    for (unsigned size = 2; size <= P; size <<= 1)
+        for (unsigned str = size >> 1; str > 0; str >>= 1) {
+            for (unsigned i = t; i < P / 2; i += 1024) {
+                const unsigned a = 2 * i - (i & (str - 1)), b = a + str;  // the pair this compare-exchange owns
+                const bool up = (a & size) == 0;
+                const unsigned long long ka = s_keys[a], kb = s_keys[b];
+                if ((ka > kb) == up) {
+                    s_keys[a] = kb;
+                    s_keys[b] = ka;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// n <= QSMALL values: one launch instead of eight (the select of a task at the reference's default 4 096
+// environments).  One block keeps the keys in registers (four per thread) and runs the same radix select,
+// eight 8-bit digits with LDS histograms; same two order statistics, same interpolation, same NaN rule.
+constexpr int QSMALL = 4096;
+__global__ __launch_bounds__(1024) void quantile_small_kernel(const double *__restrict__ x, int n, double q,
+                                                              QuantileState *states, double *out)
+{
+    __shared__ unsigned s_hist[2][256];
+    __shared__ unsigned long long s_prefix[2];
+    __shared__ unsigned s_rank[2];
+    __shared__ unsigned s_nan;
+    const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
+    unsigned long long k[4];
+    bool valid[4];
+    unsigned nans = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned i = t + c * 1024;
+        valid[c] = i < (unsigned)n;
+        const double v = valid[c] ? ld_narrow(x + i) : 0.0;
+        nans += (valid[c] && v != v) ? 1u : 0u;
+        k[c] = key_of(v);
+    }
+    const double ranks = q * (double)(n - 1);
+    const long long below = (long long)ranks;  // toType(kLong): truncation
+    const long long above = (long long)ceil(ranks);
+    if (t == 0) {
+        s_prefix[0] = s_prefix[1] = 0;
+        s_rank[0] = (unsigned)below;
+        s_rank[1] = (unsigned)above;
+        s_nan = 0;
+    }
+    if (t < 512) (&s_hist[0][0])[t] = 0;
+    __syncthreads();
+    if (nans) atomicAdd(&s_nan, nans);
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
+        const bool same = p0 == p1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (valid[c]) {
+                const unsigned long long hi = pass == 0 ? 0ull : (k[c] >> (shift + 8));
+                const unsigned d = (unsigned)(k[c] >> shift) & 255u;
+                if (hi == p0) atomicAdd(&s_hist[0][d], 1u);
+                if (!same && hi == p1) atomicAdd(&s_hist[1][d], 1u);
+            }
+        __syncthreads();
+        if (w < 2) {  // wave r finds the bin of rank r: four bins per lane, a scan over the wave
+            const unsigned *h = s_hist[(w == 1 && !same) ? 1 : 0];
+            unsigned c4[4], tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c4[i] = h[lane * 4 + i];
+                tot += c4[i];
+            }
+            unsigned inc = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(inc, off);
+                if (lane >= off) inc += v;
+            }
+            unsigned run = inc - tot;
+            const unsigned rank = s_rank[w];
+            const unsigned long long pw = w == 0 ? p0 : p1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (rank >= run && rank < run + c4[i]) {  // exactly one (lane, i)
+                    s_prefix[w] = (pw << 8) | (unsigned long long)(lane * 4 + i);
+                    s_rank[w] = rank - run;
+                }
+                run += c4[i];
+            }
+        }
+        __syncthreads();
+        if (t < 512) (&s_hist[0][0])[t] = 0;
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double wgt = ranks - (double)below;
+        const double a = value_of(s_prefix[0]), b = value_of(s_prefix[1]);
+        const double diff = b - a;
+        double r = (fabs(wgt) < 0.5) ? fma(wgt, diff, a) : fma(wgt - 1.0, diff, b);
+        if (s_nan != 0) r = __longlong_as_double(0x7ff8000000000000ll);
+        QuantileState st;
+        st.prefix[0] = s_prefix[0];
+        st.prefix[1] = s_prefix[1];
+        st.rank[0] = (unsigned long long)below;
+        st.rank[1] = (unsigned long long)above;
+        st.weight = wgt;
+        st.result = r;
+        st.n_total = (unsigned long long)n;
+        st.pad = 0;
+        states[0] = st;
+        if (out) *out = r;
+    }
+}
+
 // ---- the same select in two collectives: histogram over a shared window of the key space ----------------
 //
 // Bin 0 holds the keys below the window, bins 1 .. WBINS - 2 are 2^shift keys wide starting at `lo`, bin
@@ -469,19 +587,7 @@ __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, co
             for (unsigned j = t; j < c; j += 1024) s_keys[o + j] = g[(long long)r * num_slots + 2 + j];
         }
     __syncthreads();
-    for (unsigned size = 2; size <= P; size <<= 1)
-        for (unsigned str = size >> 1; str > 0; str >>= 1) {
-            for (unsigned i = t; i < P / 2; i += 1024) {
-                const unsigned a = 2 * i - (i & (str - 1)), b = a + str;  // the pair this compare-exchange owns
-                const bool up = (a & size) == 0;
-                const unsigned long long ka = s_keys[a], kb = s_keys[b];
-                if ((ka > kb) == up) {
-                    s_keys[a] = kb;
-                    s_keys[b] = ka;
-                }
-            }
-            __syncthreads();
-        }
+    bitonic_sort_1024(s_keys, P);
     if (t == 0) {
         WindowState n = s;
         unsigned long long k0, k1;
@@ -565,6 +671,16 @@ extern "C" int igx_quantile_finish(void *workspace, double *out, igx_stream_t st
 extern "C" int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream)
 {
     if (!out) return fail(IGX_E_NULL, "igx_quantile_f64: out is NULL");
+    static const int small_max = tuning_int("IGX_QUANTILE_SMALL_MAX", QSMALL);
+    if (n > 0 && n <= small_max && n <= QSMALL) {
+        int rc0 = check_ws(workspace, "igx_quantile_f64");
+        if (rc0 != IGX_OK) return rc0;
+        if (!x) return fail(IGX_E_NULL, "igx_quantile_f64: x is NULL");
+        if (!(q >= 0.0 && q <= 1.0)) return fail(IGX_E_PARAM, "igx_quantile_f64: q must lie in [0, 1]");
+        hipLaunchKernelGGL(quantile_small_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, (int)n, q,
+                           static_cast<QuantileState *>(workspace), out);
+        return launch_status("igx_quantile_f64");
+    }
     int rc = igx_quantile_begin(workspace, q, n, stream);
     for (int pass = 0; rc == IGX_OK && pass < IGX_QUANTILE_PASSES; ++pass)
         rc = igx_quantile_histogram(x, n, workspace, pass, stream);

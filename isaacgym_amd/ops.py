@@ -418,25 +418,32 @@ def imitate_args(motion, target_pose_idx, pose_diff, workspace, quantile, distan
                             n_total=n if n_total is None else n_total)
 
 
-def _imitate_call(symbol, params, tensors, im, n_envs):
+def _imitate_call(symbol, params, tensors, im, n_envs, cache=None):
+    """As _lib.call_step, with the imitation arguments as a third struct (`cache`: see there)."""
+    if cache is not None:
+        ids = tuple(map(id, tensors.values()))
+        ent = cache.get(symbol)
+        if ent is not None and ent[0] == ids and ent[1] == n_envs:
+            _lib.check(_lib._launch(ent[2], ent[4], C.byref(params), ent[3], C.byref(im), C.c_int64(n_envs)))
+            return
     _lib.check_sizes(_abi.LocoBuffers, params, tensors, n_envs, symbol)
     b, dev = _lib.make_buffers(_abi.LocoBuffers, tensors)
-    with torch.cuda.device(dev):
-        rc = getattr(_lib.lib(), symbol)(C.byref(params), C.byref(b), C.byref(im), C.c_int64(n_envs),
-                                         _lib.current_stream(dev))
-    _lib.check(rc)
+    fn = getattr(_lib.lib(), symbol)
+    if cache is not None:
+        cache[symbol] = (ids, n_envs, fn, C.byref(b), dev, b, list(tensors.values()))
+    _lib.check(_lib._launch(fn, dev, C.byref(params), C.byref(b), C.byref(im), C.c_int64(n_envs)))
 
 
-def ant_imitate_step(params, tensors, im, n_envs):
-    _imitate_call("igx_ant_imitate_step", params, tensors, im, n_envs)
+def ant_imitate_step(params, tensors, im, n_envs, cache=None):
+    _imitate_call("igx_ant_imitate_step", params, tensors, im, n_envs, cache)
 
 
-def ant_imitate_observe(params, tensors, im, n_envs):
-    _imitate_call("igx_ant_imitate_observe", params, tensors, im, n_envs)
+def ant_imitate_observe(params, tensors, im, n_envs, cache=None):
+    _imitate_call("igx_ant_imitate_observe", params, tensors, im, n_envs, cache)
 
 
-def ant_imitate_finish(params, tensors, im, n_envs):
-    _imitate_call("igx_ant_imitate_finish", params, tensors, im, n_envs)
+def ant_imitate_finish(params, tensors, im, n_envs, cache=None):
+    _imitate_call("igx_ant_imitate_finish", params, tensors, im, n_envs, cache)
 
 
 def quantile_f64(x, q, workspace=None):

@@ -32,6 +32,7 @@ class AntImitate(Ant):
         self._pose_diff = torch.zeros(self.num_envs, device=self.device, dtype=torch.float64)
         self._qws = torch.empty(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=self.device)
         self._group = process_group
+        self._im = None
         self._n_total = None  # environments of all ranks (asked once)
         self._window = None
         self.quantile_collectives = self.cfg["env"].get("quantileCollectives", "window")
@@ -39,23 +40,28 @@ class AntImitate(Ant):
             raise ValueError("env.quantileCollectives must be 'window' or 'radix'")
 
     def _imitate_args(self, n_total):
-        return ops.imitate_args(self.motion_to_imitate, self.target_pose_idx, self._pose_diff, self._qws,
-                                self.QUANTILE_THRESHOLD, self.DISTANCE_FLOOR, float(self.death_cost), n_total)
+        key = (n_total, float(self.death_cost))
+        if self._im is None or self._im[0] != key:  # the tensors it points at live as long as the task
+            self._im = (key, ops.imitate_args(self.motion_to_imitate, self.target_pose_idx, self._pose_diff, self._qws,
+                                              self.QUANTILE_THRESHOLD, self.DISTANCE_FLOOR, float(self.death_cost), n_total))
+        return self._im[1]
 
     def post_physics_step(self):
         # ant_imitate.py reset_idx re-randomises like Ant's, i.e. on steps where some env is reset
         if self.randomize and bool(self.reset_buf.any()):
             self.apply_randomizations(self.randomization_params)
         world = distributed.world_size(self._group)
+        p, b = self._params(), self._buffers()
+        if self._can_fuse_tail():  # the clamped copy (observe kernel) and the time-out flags (finish kernel)
+            self._fuse_tail(p, b)
         if world == 1:
-            ops.ant_imitate_step(self._params(), self._buffers(), self._imitate_args(self.num_envs), self.num_envs)
+            ops.ant_imitate_step(p, b, self._imitate_args(self.num_envs), self.num_envs, self._call_cache)
         else:
             if self._n_total is None:
                 counts = distributed.gather_records(torch.tensor([self.num_envs], device=self.device), self._group)
                 self._n_total = int(counts.sum())
             im = self._imitate_args(self._n_total)
-            p, b = self._params(), self._buffers()
-            ops.ant_imitate_observe(p, b, im, self.num_envs)
+            ops.ant_imitate_observe(p, b, im, self.num_envs, self._call_cache)
             done = False
             if self.quantile_collectives == "window" and self._n_total < (1 << 31):
                 if self._window is None:
@@ -68,7 +74,7 @@ class AntImitate(Ant):
             if not done:
                 ops.quantile_sharded(self._pose_diff, self.QUANTILE_THRESHOLD, self._n_total, self._qws,
                                      lambda h: distributed.all_reduce_sum(h, self._group))
-            ops.ant_imitate_finish(p, b, im, self.num_envs)
+            ops.ant_imitate_finish(p, b, im, self.num_envs, self._call_cache)
         self.extras["true_objective"] = self._true_objective
 
     @property

@@ -474,9 +474,10 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
         b->reset[e] = rst;
         b->progress[e] = prog;
         if (b->true_objective) b->true_objective[e] = root[7];
-        /* the tail of VecTask.step (tasks/base/vec_task.py:404, :412), not for the imitation variants */
+        /* the tail of VecTask.step (tasks/base/vec_task.py:404, :412); the imitation variant decides its
+         * time-out flag in orc_ant_imitate_finish, after the threshold has set the last reset flags */
         if (!im && b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && rst != 0) ? 1 : 0;
-        if (!im && b->obs_clamped) {
+        if (b->obs_clamped) {
             for (int c = 0; c < NOBS; ++c) { /* torch.clamp: NaN stays NaN */
                 float v = obs[c];
                 v = v < -p->clip_obs ? -p->clip_obs : v;
@@ -1972,7 +1973,8 @@ int orc_ant_imitate_observe(const igx_loco_params *p, const igx_loco_buffers *b,
 }
 
 /* tasks/ant_imitate.py:523-555 given the global threshold */
-int orc_ant_imitate_finish(const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n, double quantile_value)
+int orc_ant_imitate_finish(const igx_loco_params *p, const igx_loco_buffers *b, const igx_imitate_args *im, int64_t n,
+                           double quantile_value)
 {
     /* Python's max(1.8, quantile): the second argument only if it compares greater (a NaN quantile leaves 1.8) */
     double thr = quantile_value > im->distance_floor ? quantile_value : im->distance_floor;
@@ -1988,6 +1990,8 @@ int orc_ant_imitate_finish(const igx_loco_buffers *b, const igx_imitate_args *im
             idx = 0;
         }
         im->target_pose_idx[e] = idx;
+        if (b->time_outs) /* vec_task.py:404 on the flags as they are now */
+            b->time_outs[e] = ((float)b->progress[e] >= p->max_episode_length_m1 && b->reset[e] != 0) ? 1 : 0;
     }
     return 0;
 }

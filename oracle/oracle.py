@@ -405,16 +405,16 @@ def ant_imitate_observe(params, bufs, im, n):
     assert lib().orc_ant_imitate_observe(C.byref(params), C.byref(b), C.byref(im), C.c_int64(n)) == 0
 
 
-def ant_imitate_finish(bufs, im, n, quantile_value):
+def ant_imitate_finish(params, bufs, im, n, quantile_value):
     b = _abi.make_buffers(_abi.LocoBuffers, bufs, _np_ptr)
-    assert lib().orc_ant_imitate_finish(C.byref(b), C.byref(im), C.c_int64(n), C.c_double(quantile_value)) == 0
+    assert lib().orc_ant_imitate_finish(C.byref(params), C.byref(b), C.byref(im), C.c_int64(n), C.c_double(quantile_value)) == 0
 
 
 def ant_imitate_step(params, bufs, im, arrays, n):
     """One GPU's worth: observe, global quantile, finish.  Returns the quantile value."""
     ant_imitate_observe(params, bufs, im, n)
     qv = quantile_f64(arrays["pose_diff"][:n], im.quantile)
-    ant_imitate_finish(bufs, im, n, qv)
+    ant_imitate_finish(params, bufs, im, n, qv)
     return qv
 
 

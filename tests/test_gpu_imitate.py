@@ -32,6 +32,24 @@ def test_quantile_equals_torch(n, q):
     assert float(got) == float(torch.quantile(x.cpu(), q)), (n, q)
 
 
+def test_quantile_one_block_path_equals_torch_on_ties_and_signs():
+    """n <= 4096 takes the one-launch select: every size around the per-thread layout, ties, signed zeros, inf."""
+    gen = torch.Generator().manual_seed(77)
+    for n in (1, 2, 5, 63, 64, 65, 1023, 1024, 1025, 2048, 3000, 4095, 4096):
+        for kind in range(4):
+            x = torch.randn(n, generator=gen, dtype=torch.float64)
+            if kind == 1:
+                x = torch.round(x * 2) / 2          # heavy ties, -0.0 and 0.0
+            elif kind == 2:
+                x[::3] = float("inf")
+                x[1::7] = -float("inf")
+            elif kind == 3:
+                x = torch.full((n,), -1.5, dtype=torch.float64)
+            for q in (0.0, 0.25, 0.5, 0.99, 1.0, float(torch.rand((), generator=gen))):
+                got, want = float(ops.quantile_f64(x.to(DEV), q)), float(torch.quantile(x, q))
+                assert got == want or (np.isnan(got) and np.isnan(want)), (n, kind, q, got, want)
+
+
 def test_quantile_sharded_equals_whole():
     n = 300001
     x = torch.rand(n, device=DEV, dtype=torch.float64) ** 3
@@ -118,6 +136,11 @@ def test_ant_imitate_vs_oracle(n):
     arrays = dict(motion=lo + (hi - lo) * torch.rand(F, 8, generator=gen, device=DEV, dtype=torch.float64),
                   target_pose_idx=torch.randint(0, F - 1, (n,), generator=gen, device=DEV),
                   pose_diff=torch.zeros(n, dtype=torch.float64, device=DEV))
+    # the tail of VecTask.step in the same launches: clamped observations (observe), time-out flags (finish)
+    p.clip_obs = 0.7
+    p.max_episode_length_m1 = 600.0
+    t["obs_clamped"] = torch.full((n, 60), 9.0, device=DEV)
+    t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
     ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
     ref_arrays = {k: v.cpu().numpy().copy() for k, v in arrays.items()}
     ws = _ws()
@@ -131,8 +154,13 @@ def test_ant_imitate_vs_oracle(n):
         assert float(ws.view(torch.float64)[5]) == qv
         assert np.array_equal(arrays["pose_diff"].cpu().numpy().view(np.uint64), ref_arrays["pose_diff"].view(np.uint64))
         assert np.array_equal(arrays["target_pose_idx"].cpu().numpy(), ref_arrays["target_pose_idx"])
-        for k in ("reset", "progress", "randomize"):
+        for k in ("reset", "progress", "randomize", "time_outs"):
             assert np.array_equal(t[k].cpu().numpy(), ref[k]), k
+        assert np.array_equal(ref["time_outs"], (ref["progress"].astype(np.float32) >= 600.0) & (ref["reset"] != 0))
+        assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -0.7, 0.7))
+        assert np.array_equal(ref["obs_clamped"], np.clip(ref["obs"], -0.7, 0.7))
+        if n >= 50001:
+            assert 0 < int(ref["time_outs"].sum()) < n
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what="rew")
         for k in ("dof_state", "potentials", "prev_potentials"):
             assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k

@@ -319,7 +319,9 @@ def test_ant_imitate_class_golden():
     for t in range(T):
         task.reset_buf.copy_(dev(g["in_reset"][t]))
         task.reset_rand = dev(g["rand"][t])
-        _, rew, reset, _ = task.step(dev(g["in_actions"][t]))
+        obs_dict, rew, reset, extras = task.step(dev(g["in_actions"][t]))
+        assert torch.equal(obs_dict["obs"], torch.clamp(task.obs_buf, -task.clip_obs, task.clip_obs))
+        assert torch.equal(extras["time_outs"], (task.progress_buf >= task.max_episode_length - 1) & (reset != 0))
         assert task.pose_threshold == float(g["threshold"][t])
         assert np.array_equal(host(reset), g["reset"][t]) and np.array_equal(host(task.progress_buf), g["progress"][t])
         assert np.array_equal(host(task.target_pose_idx), g["target_pose_idx"][t])

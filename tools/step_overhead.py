@@ -9,9 +9,34 @@ from isaacgym_amd import tasks
 from isaacgym_amd.graph import GraphedStep
 
 DEV = "cuda:0"
+_motion_lib = None
+
+
+def make(name, n):
+    """tasks.make, with a synthetic clip for HumanoidAMP (the reference's motion files are not in the tree)."""
+    global _motion_lib
+    if name != "HumanoidAMP":
+        return tasks.make(name, n, DEV)
+    import os
+    import tempfile
+    from isaacgym_amd import cfg as C
+    from isaacgym_amd.sim import SyntheticSim
+    from isaacgym_amd.tasks.amp.utils_amp.motion_lib import MotionLib
+    if _motion_lib is None:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from tests import helpers as H
+        path = H.write_golden_motions(H.load_golden("motion"), tempfile.mkdtemp())
+        _motion_lib = MotionLib(path, 28, [5, 8, 11, 14], DEV)
+    cfg = C.task_config("HumanoidAMP", n)
+    sim = SyntheticSim("HumanoidAMP", n, DEV, seed=7, num_amp_obs_steps=cfg["env"]["numAMPObsSteps"])
+    return tasks.HumanoidAMP(cfg, DEV, DEV, sim=sim, motion_lib=_motion_lib)
+
+
 for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 8), ("Humanoid", 4096, 21),
-                      ("AllegroHand", 4096, 16), ("ShadowHand", 4096, 20)):
-    t = tasks.make(name, n, DEV)
+                      ("AllegroHand", 4096, 16), ("ShadowHand", 4096, 20), ("HumanoidAMP", 4096, 28),
+                      ("AntImitate", 4096, 8), ("HumanoidImitate", 4096, 63)):
+    t = make(name, n)
     a = torch.zeros(n, acts, device=DEV)
     for _ in range(20):
         t.step(a)
@@ -30,7 +55,7 @@ for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 
             (name, n, host, wall, e0.elapsed_time(e1) / k * 1e3))
     # the stand-in simulator copies a fresh state set into the shared tensors every simulate(); with an engine
     # that writes its tensors in place (here: a simulate() that does nothing) the step is this package's code alone
-    t2 = tasks.make(name, n, DEV)
+    t2 = make(name, n)
     t2.sim.simulate = lambda: None
     for _ in range(20):
         t2.step(a)
@@ -41,7 +66,7 @@ for name, n, acts in (("Cartpole", 4096, 1), ("Ant", 4096, 8), ("Ant", 1 << 20, 
     torch.cuda.synchronize()
     line += "  | in-place sim: wall %.1f us/step" % ((time.perf_counter() - t0) / k * 1e6)
     # the same step recorded once into a HIP graph and replayed
-    g = GraphedStep(tasks.make(name, n, DEV))
+    g = GraphedStep(make(name, n))
     for _ in range(20):
         g.step(a)
     torch.cuda.synchronize()
