@@ -59,7 +59,7 @@ typedef struct igx_cartpole_params {
     float max_episode_length_m1;  /* max_episode_length - 1 = 499 */
     int32_t reward_variant;       /* 0: tasks/cartpole.py:185-201; 1: tasks/cartpole_sample.py:316-335
                                      (1 - 0.001 a^2 - 0.001|cart_vel| - 0.001|pole_vel|) */
-    int32_t reserved;
+    float clip_obs;               /* env.clipObservations (5.0), used only when obs_clamped is given */
     uint64_t seed;                /* in-kernel Philox key when rand == NULL */
     uint64_t rng_offset;          /* step counter mixed into the Philox counter */
     const uint64_t *rng_offset_dev; /* optional device-resident counter added to rng_offset when the kernel draws:
@@ -77,6 +77,9 @@ typedef struct igx_cartpole_buffers {
     float *rew;          /* [N] out */
     int64_t *reset;      /* [N] in/out */
     int64_t *progress;   /* [N] in/out */
+    /* optional: the tail of VecTask.step (vec_task.py:404, :412) in the same launch; NULL skips */
+    float *obs_clamped;  /* [N,4] clamp(obs, -clip_obs, clip_obs); must not alias obs */
+    uint8_t *time_outs;  /* [N] bool (progress >= max_episode_length - 1) & (reset != 0) after the step */
 } igx_cartpole_buffers;
 
 /* Cartpole.reset_idx (tasks/cartpole.py:148-162) for an explicit list of m

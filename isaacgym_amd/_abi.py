@@ -43,13 +43,13 @@ class _Struct(C.Structure):
 
 class CartpoleParams(_Struct):
     _fields_ = [("reset_dist", f32), ("max_episode_length_m1", f32),
-                ("reward_variant", i32), ("reserved", i32),
+                ("reward_variant", i32), ("clip_obs", f32),
                 ("seed", u64), ("rng_offset", u64), ("rng_offset_dev", ptr), ("env_offset", i64)]
 
 
 class CartpoleBuffers(_Struct):
     _fields_ = [("dof_state", ptr), ("rand", ptr), ("obs", ptr), ("rew", ptr),
-                ("reset", ptr), ("progress", ptr)]
+                ("reset", ptr), ("progress", ptr), ("obs_clamped", ptr), ("time_outs", ptr)]
 
 
 class LocoParams(_Struct):
@@ -325,7 +325,8 @@ _ONE = _env(1)
 
 
 def _cartpole_widths(p):
-    return dict(dof_state=_env(4), rand=_env(4), obs=_env(4), rew=_ONE, reset=_ONE, progress=_ONE)
+    return dict(dof_state=_env(4), rand=_env(4), obs=_env(4), rew=_ONE, reset=_ONE, progress=_ONE,
+                obs_clamped=_env(4), time_outs=_ONE)
 
 
 def _loco_widths(p):

@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256) void cartpole_step_kernel(const igx_cartpole_p
     b.rew[e] = reward;
     b.reset[e] = rst;
     b.progress[e] = prog;
+    if (b.obs_clamped) {
+        const float c = p.clip_obs;
+        reinterpret_cast<float4 *>(b.obs_clamped)[e] =
+            float4{clamp1(ds.x, -c, c), clamp1(ds.y, -c, c), clamp1(ds.z, -c, c), clamp1(ds.w, -c, c)};
+    }
+    if (b.time_outs) b.time_outs[e] = ((float)prog >= p.max_episode_length_m1 && rst != 0) ? 1 : 0;
 }
 
 // reset_idx on an explicit id list: one lane per listed environment
@@ -113,6 +119,11 @@ extern "C" int igx_cartpole_step(const igx_cartpole_params *p, const igx_cartpol
     IGX_REQUIRE_ALIGNED(b->dof_state, "dof_state");
     IGX_REQUIRE_ALIGNED(b->obs, "obs");
     if (b->rand) IGX_REQUIRE_ALIGNED(b->rand, "rand");
+    if (b->obs_clamped) {
+        IGX_REQUIRE_ALIGNED(b->obs_clamped, "obs_clamped");
+        if (!(p->clip_obs >= 0.0f) || b->obs_clamped == b->obs)
+            return igx::fail(IGX_E_PARAM, "igx_cartpole_step: obs_clamped needs clip_obs >= 0 and must not alias obs");
+    }
     const int64_t blocks = (n_envs + 255) / 256;
     hipLaunchKernelGGL(igx::cartpole_step_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *p, *b, n_envs);

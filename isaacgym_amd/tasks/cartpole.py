@@ -49,7 +49,10 @@ class Cartpole(VecTask):
         self.sim.apply_dof_forces(self._forces)
 
     def post_physics_step(self):
-        ops.cartpole_step(self._params(), self._buffers(), self.num_envs, self._call_cache)
+        p, b = self._params(), self._buffers()
+        if self._can_fuse_tail():  # the clamped copy and the time-out flags of VecTask.step in the same launch
+            self._fuse_tail(p, b)
+        ops.cartpole_step(p, b, self.num_envs, self._call_cache)
 
     def reset_idx(self, env_ids):
         ops.cartpole_reset(self._params(), self._buffers(), env_ids.to(self.device, torch.int64).contiguous())

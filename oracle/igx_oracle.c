@@ -266,6 +266,14 @@ int orc_cartpole_step(const igx_cartpole_params *p, const igx_cartpole_buffers *
         b->rew[e] = reward;
         b->reset[e] = rst;
         b->progress[e] = prog;
+        /* the tail of VecTask.step (tasks/base/vec_task.py:404, :412) */
+        if (b->obs_clamped)
+            for (int c = 0; c < 4; ++c) { /* torch.clamp: NaN stays NaN */
+                float v = b->obs[e * 4 + c];
+                v = v < -p->clip_obs ? -p->clip_obs : v;
+                b->obs_clamped[e * 4 + c] = v > p->clip_obs ? p->clip_obs : v;
+            }
+        if (b->time_outs) b->time_outs[e] = ((float)prog >= p->max_episode_length_m1 && rst != 0) ? 1 : 0;
     }
     return 0;
 }

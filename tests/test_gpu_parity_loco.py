@@ -52,6 +52,29 @@ def test_cartpole_vs_oracle(n, with_rand):
         assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k
 
 
+def test_cartpole_writes_the_step_tail_in_the_same_launch():
+    """obs_clamped / time_outs (the tail of VecTask.step) out of the step kernel, against the CPU restatement."""
+    n = 70001
+    p = synthetic.cartpole_params(seed=5, rng_offset=1)
+    p.clip_obs = 0.8
+    t = synthetic.cartpole_state(n, 4, DEV, True)
+    t["progress"][::5] = 498
+    t["obs_clamped"] = torch.full((n, 4), 9.0, device=DEV)
+    t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    ops.cartpole_step(p, t, n)
+    oracle.cartpole_step(p, ref, n)
+    for k in ("reset", "progress", "time_outs"):
+        assert np.array_equal(t[k].cpu().numpy(), ref[k]), k
+    assert 0 < int(ref["time_outs"].sum()) < n
+    assert np.array_equal(ref["time_outs"], (ref["progress"] >= 499) & (ref["reset"] != 0))
+    assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -0.8, 0.8))
+    assert np.array_equal(ref["obs_clamped"], np.clip(ref["obs"], -0.8, 0.8))
+    t["obs_clamped"] = t["obs"]
+    with pytest.raises(RuntimeError, match="alias"):
+        ops.cartpole_step(p, t, n)
+
+
 def _golden_loco(name, step, nobs, humanoid):
     g = H.load_golden(name)
     m = g["meta"]
