@@ -5,8 +5,6 @@ feed the step kernels with tensors drawn here (distributions chosen so that
 every branch is exercised: ~0.5 % of envs below the termination height, a few
 % of joints beyond the soft limits, ~0.1 % of envs timing out per step).
 """
-import math
-
 import torch
 
 from . import _abi

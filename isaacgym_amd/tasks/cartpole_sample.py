@@ -7,8 +7,6 @@ Camera rendering (`use_cam`, `is_train: False`) belongs to the simulator and has
 counterpart here."""
 import os
 
-import torch
-
 from ..recorder import TrajectoryRecorder
 from .cartpole import Cartpole
 

@@ -1601,7 +1601,6 @@ def gen_prestep(seed=61, N=127, T=4):
     (tasks/base/vec_task.py:381-384, :407-412, :630-729)."""
     import contextlib
     import copy
-    import types
     _install_gym_stubs()
     sys.modules["isaacgym.gymtorch"].unwrap_tensor = lambda t: t
     g = torch.Generator().manual_seed(seed)
