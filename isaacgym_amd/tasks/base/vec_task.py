@@ -114,6 +114,9 @@ class VecTask:
     def action_space(self):
         return dict(low=-1.0, high=1.0, shape=(self.num_actions,))
 
+    def get_number_of_agents(self):  # what RLGPUEnv asks its environment (utils/rlgames_utils.py:257-258)
+        return self.num_agents
+
     def set_train_info(self, env_frames, *args, **kwargs):
         self.total_train_env_frames = env_frames
 

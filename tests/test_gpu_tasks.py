@@ -612,3 +612,25 @@ def test_fresh_step_outputs_do_not_alias_the_next_step(name):
     assert torch.equal(o1["obs"], keep[0]) and torch.equal(r1, keep[1]) and torch.equal(d1, keep[2])
     assert o2["obs"].data_ptr() != o1["obs"].data_ptr() and not torch.equal(o2["obs"], o1["obs"])
     assert torch.equal(o2["obs"], p2[0]["obs"]) and p2[0]["obs"].data_ptr() == p1[0]["obs"].data_ptr()
+
+
+def test_rlgpu_env_over_a_real_task():
+    """The learner's view (RLGPUEnv <- get_rlgames_env_creator) of an Ant task on the device."""
+    from isaacgym_amd.utils import rlgames_utils as R
+    n = 512
+    cfg = C.task_config("Ant", n)
+    make = R.get_rlgames_env_creator(3, cfg, "Ant", DEV, DEV, sim=SyntheticSim("Ant", n, DEV, seed=3))
+    R.env_configurations.register("rlgpu", {"vecenv_type": "RLGPU", "env_creator": lambda **kw: make()})
+    env = R.RLGPUEnv("rlgpu", 1)
+    info = env.get_env_info()
+    assert info["observation_space"]["shape"] == (60,) and info["action_space"]["shape"] == (8,) and "state_space" not in info
+    assert env.get_number_of_agents() == 1 and env.env.env_offset == 0
+    first = env.reset()
+    assert first["obs"].shape == (n, 60)
+    env.reset_done()
+    obs, rew, done, extras = env.step(torch.zeros(n, 8, device=DEV))
+    assert obs["obs"].shape == (n, 60) and rew.shape == (n,) and done.dtype == torch.int64 and "time_outs" in extras
+    twin = tasks.make("Ant", n, DEV, seed=3)
+    twin.reset_done()
+    want = twin.step(torch.zeros(n, 8, device=DEV))
+    assert torch.equal(obs["obs"], want[0]["obs"]) and torch.equal(rew, want[1]) and torch.equal(done, want[2])
