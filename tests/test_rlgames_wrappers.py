@@ -89,3 +89,21 @@ def test_multi_observer_fans_out():
     assert a.seen == b.seen and [n for n, _ in a.seen] == ["before_init", "after_init", "process_infos", "after_steps",
                                                             "after_clear_stats", "after_print_stats"]
     assert a.seen[-1][1] == (10, 2, 1.5)
+
+
+def test_set_seed_follows_the_reference_rule():
+    import random
+
+    import numpy as np
+    import torch
+
+    from isaacgym_amd.utils import utils as U
+    assert U.resolve_seed(-1, True, 3) == 45 and U.resolve_seed(7, False, 2) == 9 and 0 <= U.resolve_seed(-1, False) < 10000
+    try:
+        assert U.set_seed(5, rank=1) == 6
+        a = (random.random(), float(np.random.rand()), float(torch.rand(())))
+        assert U.set_seed(6) == 6
+        assert (random.random(), float(np.random.rand()), float(torch.rand(()))) == a
+        assert U.flatten_dict({"a": {"b": 1}, "c": 2}) == {"a.b": 1, "c": 2}
+    finally:
+        torch.use_deterministic_algorithms(False)
