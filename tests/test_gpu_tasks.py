@@ -634,3 +634,55 @@ def test_rlgpu_env_over_a_real_task():
     twin.reset_done()
     want = twin.step(torch.zeros(n, 8, device=DEV))
     assert torch.equal(obs["obs"], want[0]["obs"]) and torch.equal(rew, want[1]) and torch.equal(done, want[2])
+
+
+def test_task_built_from_a_hydra_style_task_file(tmp_path):
+    """A task file in the reference's format (interpolations and all) is enough to construct and step the task."""
+    text = """
+name: Ant
+physics_engine: ${..physics_engine}
+env:
+  numEnvs: ${resolve_default:4096,${...num_envs}}
+  envSpacing: 5
+  episodeLength: 1000
+  enableDebugVis: False
+  clipActions: 1.0
+  powerScale: 1.0
+  controlFrequencyInv: 1 # 60 Hz
+  headingWeight: 0.5
+  upWeight: 0.1
+  actionsCost: 0.005
+  energyCost: 0.05
+  dofVelocityScale: 0.2
+  contactForceScale: 0.1
+  jointsAtLimitCost: 0.1
+  deathCost: -2.0
+  terminationHeight: 0.31
+  plane:
+    staticFriction: 1.0
+    dynamicFriction: 1.0
+    restitution: 0.0
+  enableCameraSensors: False
+sim:
+  dt: 0.0166 # 1/60 s
+  substeps: 2
+  up_axis: "z"
+  use_gpu_pipeline: ${eq:${...pipeline},"gpu"}
+  gravity: [0.0, 0.0, -9.81]
+  physx:
+    num_threads: ${....num_threads}
+    use_gpu: ${contains:"cuda",${....sim_device}}
+task:
+  randomize: False
+"""
+    p = tmp_path / "Ant.yaml"
+    p.write_text(text)
+    cfg = C.load_task_yaml(str(p), num_envs=700, sim_device=DEV)
+    assert cfg["env"]["numEnvs"] == 700 and cfg["sim"]["physx"]["use_gpu"] is True
+    task = tasks.Ant(cfg, DEV, DEV, sim=SyntheticSim("Ant", 700, DEV, seed=5), seed=5)
+    twin = tasks.make("Ant", 700, DEV, seed=5)
+    for t in (task, twin):
+        t.reset_done()
+    a = torch.rand(700, 8, device=DEV) * 2 - 1
+    got, want = task.step(a), twin.step(a)
+    assert torch.equal(got[0]["obs"], want[0]["obs"]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
