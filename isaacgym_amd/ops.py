@@ -479,6 +479,9 @@ def quantile_sharded(x, q, n_total, workspace, all_reduce):
     return workspace.view(torch.float64)[5].clone()
 
 
+_STATUS_WORD = 19  # int32 index of WindowState::status in the workspace (quantile.hip)
+
+
 class WindowQuantile:
     """torch.quantile over the shards of a multi-GPU job in two collectives: one all-reduce of a 16 384-bin
     histogram over a window of the key space that all ranks share, one all-gather of the keys in the bin
@@ -560,6 +563,11 @@ class WindowQuantile:
                 gathered = all_gather(self.slots[:num_slots]).contiguous()
                 self.collectives += 1
                 self.finish(gathered, gathered.shape[0], num_slots, out)
+                if _lib.DEBUG_CHECKS:  # synchronises: the finish kernel marks a gather that does not add up
+                    state = int(self.workspace[_STATUS_WORD])
+                    if state not in (_abi.IGX_QW_COLLECT, _abi.IGX_QW_VALUE):
+                        raise RuntimeError("window quantile: the gathered slots do not hold the located bin "
+                                           "(status %d); did every rank gather the same tensor?" % state)
                 return True
             break
         self.fallbacks += 1

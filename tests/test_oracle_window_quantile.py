@@ -100,3 +100,22 @@ def test_give_up_is_reported_and_forgets_the_window():
     assert ok is False and obj.fallbacks == 1
     assert obj.run(x, 0.5, 1000, lambda t: None, lambda t: t.unsqueeze(0)) is True
     assert float(obj.result()) == float(torch.quantile(x, 0.5))
+
+
+def test_debug_checks_catch_a_gather_that_does_not_add_up(monkeypatch):
+    """With IGX_DEBUG_CHECKS the protocol reads the state back after the finish: slots that do not hold the located
+    bin (here: a gather that returns only this rank's slots for both ranks' worth of keys) raise instead of
+    leaving a NaN threshold behind."""
+    from isaacgym_amd import _lib
+    rng = np.random.default_rng(10)
+    x = torch.from_numpy(rng.standard_normal(4000))
+    obj = oracle_window_quantile()
+    ok = obj.run(x[:2000].contiguous(), 0.5, 4000, lambda t: t.mul_(2), lambda t: t.unsqueeze(0))  # "two ranks", one gathered
+    assert ok and np.isnan(float(obj.result()))
+    monkeypatch.setattr(_lib, "DEBUG_CHECKS", True)
+    obj = oracle_window_quantile()
+    with pytest.raises(RuntimeError, match="do not hold the located bin"):
+        obj.run(x[:2000].contiguous(), 0.5, 4000, lambda t: t.mul_(2), lambda t: t.unsqueeze(0))
+    obj = oracle_window_quantile()
+    assert obj.run(x, 0.5, 4000, lambda t: t, lambda t: t.unsqueeze(0))
+    assert float(obj.result()) == float(torch.quantile(x, 0.5))
