@@ -60,6 +60,15 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
+# A world of one needs no collective and the helpers below return at once.  Setting this makes them call the
+# backend all the same (when a group is initialised): the only way to run the RCCL calls on a one-GPU machine.
+FORCE_COLLECTIVES = False
+
+
+def _alone(group=None):
+    return world_size(group) == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -74,7 +83,7 @@ def gather_records(record, group=None):
     """All-gather one fixed-size record per rank: 1-D tensor [R] -> [world, R], rank order."""
     record = record.contiguous()
     w = world_size(group)
-    if w == 1:
+    if _alone(group):
         return record.unsqueeze(0).clone()
     flat = record.reshape(-1)
     dev = record.device
@@ -89,7 +98,7 @@ def all_gather_rows(rows, group=None):
     """Concatenate equally sized per-rank batches [n, ...] -> [world * n, ...], rank order."""
     rows = rows.contiguous()
     w = world_size(group)
-    if w == 1:
+    if _alone(group):
         return rows
     dev = rows.device
     if dev.type != "cpu" and _host_backend(group):
@@ -102,7 +111,7 @@ def all_gather_rows(rows, group=None):
 def all_reduce_sum(t, group=None):
     """Sum an integer tensor over the ranks in place (counts of a histogram: the order of the additions cannot
     change the bits).  Device tensors travel through the host under a host-only backend."""
-    if world_size(group) == 1:
+    if _alone(group):
         return t
     if t.device.type != "cpu" and _host_backend(group):
         h = t.cpu()
