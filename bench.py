@@ -47,6 +47,9 @@ def parse():
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this device index instead of LOCAL_RANK")
+    ap.add_argument("--force-group", action="store_true",
+                    help="rehearsal only: join a process group even as a single rank, so that the barrier and the MAX "
+                         "of the N > 1 path run through the backend on a one-GPU box")
     ap.add_argument("--episode-stats", action="store_true",
                     help="also run the episode-statistics kernel every step (inside the timed region) and "
                          "all-gather the totals over the ranks afterwards")
@@ -176,7 +179,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = args.backend
-    if world > 1:
+    grouped = world > 1 or args.force_group
+    if grouped:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
         backend = init_group(dist, torch, args.backend, dev)
 
     spec = synthetic.ANT if args.task == "ant" else synthetic.HUMANOID
@@ -214,7 +220,7 @@ def main():
                 es.step(sets[0]["rew"], sets[0]["reset"])
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +240,7 @@ def main():
     else:
         kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per launch on the launch stream
 
-    if world > 1:
+    if grouped:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -255,7 +261,7 @@ def main():
                                    "layout, in-kernel Philox resets" % (args.task, n),
                        "envs_per_gpu": n, "global_envs": n * world, "input_sets": NUM_INPUT_SETS,
                        "parallelism": "env-shard x%d (no data-path collective)" % world,
-                       "collective_backend": backend if world > 1 else None},
+                       "collective_backend": backend if grouped else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": load_traffic() if args.task == "ant" and n == ENVS_PER_GPU else None,
@@ -269,7 +275,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, n, args.task)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
