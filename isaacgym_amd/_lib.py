@@ -53,6 +53,7 @@ SYMBOLS.update({
     "igx_quantile_histogram": (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P]),
     "igx_quantile_finish": (C.c_int, [_P, _P, _P]),
     "igx_quantile_f64": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
+    "igx_quantile_f64_windowed": (C.c_int, [_P, C.c_int64, C.c_double, _P, _P, _P]),
     "igx_quantile_window_begin": (C.c_int, [_P, C.c_double, C.c_int64, C.c_int32, _P]),
     "igx_quantile_window_histogram": (C.c_int, [_P, C.c_int64, _P, _P]),
     "igx_quantile_window_locate": (C.c_int, [_P, C.c_int32, _P, _P]),

@@ -626,7 +626,7 @@ extern "C" int igx_ant_imitate_step(const igx_loco_params *p, const igx_loco_buf
     int rc = igx_ant_imitate_observe(p, b, im, n_envs, stream);
     if (rc != IGX_OK || n_envs == 0) return rc;
     double *result = reinterpret_cast<double *>(im->workspace) + 5;  // the quantile lands in the state itself
-    rc = igx_quantile_f64(im->pose_diff, n_envs, im->quantile, result, im->workspace, stream);
+    rc = igx_quantile_f64_windowed(im->pose_diff, n_envs, im->quantile, result, im->workspace, stream);
     if (rc != IGX_OK) return rc;
     return igx_ant_imitate_finish(p, b, im, n_envs, stream);
 }

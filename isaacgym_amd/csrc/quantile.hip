@@ -210,56 +210,81 @@ __device__ __forceinline__ void bitonic_sort_1024(unsigned long long *s_keys, un
         }
 }
 
-// n <= QSMALL values: one launch instead of eight (the select of a task at the reference's default 4 096
-// environments).  One block keeps the keys in registers (four per thread) and runs the same radix select,
-// eight 8-bit digits with LDS histograms; same two order statistics, same interpolation, same NaN rule.
+// The whole select by ONE workgroup of 1024 threads: eight 8-bit digits with LDS histograms, the same two order
+// statistics as the multi-pass kernels.  REG: n <= 4096 and every thread keeps its four keys in registers;
+// otherwise the values are streamed from memory once per digit.  Leaves the two keys in s_prefix and the NaN
+// count in *s_nan (all in LDS, valid after the call's final barrier).
 constexpr int QSMALL = 4096;
-__global__ __launch_bounds__(1024) void quantile_small_kernel(const double *__restrict__ x, int n, double q,
-                                                              QuantileState *states, double *out)
+struct BlockSelect {
+    unsigned hist[2][256];
+    unsigned long long prefix[2];
+    unsigned rank[2];
+    unsigned nan;
+};
+
+template <bool REG>
+__device__ __forceinline__ void block_select(const double *__restrict__ x, int64_t n, long long below, long long above,
+                                             BlockSelect &s)
 {
-    __shared__ unsigned s_hist[2][256];
-    __shared__ unsigned long long s_prefix[2];
-    __shared__ unsigned s_rank[2];
-    __shared__ unsigned s_nan;
     const unsigned t = threadIdx.x, lane = t & 63, w = t >> 6;
-    unsigned long long k[4];
-    bool valid[4];
+    unsigned long long k[4] = {0, 0, 0, 0};
+    bool valid[4] = {false, false, false, false};
     unsigned nans = 0;
+    if (REG) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const unsigned i = t + c * 1024;
-        valid[c] = i < (unsigned)n;
-        const double v = valid[c] ? ld_narrow(x + i) : 0.0;
-        nans += (valid[c] && v != v) ? 1u : 0u;
-        k[c] = key_of(v);
+        for (int c = 0; c < 4; ++c) {
+            const unsigned i = t + c * 1024;
+            valid[c] = (int64_t)i < n;
+            const double v = valid[c] ? ld_narrow(x + i) : 0.0;
+            nans += (valid[c] && v != v) ? 1u : 0u;
+            k[c] = key_of(v);
+        }
     }
-    const double ranks = q * (double)(n - 1);
-    const long long below = (long long)ranks;  // toType(kLong): truncation
-    const long long above = (long long)ceil(ranks);
     if (t == 0) {
-        s_prefix[0] = s_prefix[1] = 0;
-        s_rank[0] = (unsigned)below;
-        s_rank[1] = (unsigned)above;
-        s_nan = 0;
+        s.prefix[0] = s.prefix[1] = 0;
+        s.rank[0] = (unsigned)below;
+        s.rank[1] = (unsigned)above;
+        s.nan = 0;
     }
-    if (t < 512) (&s_hist[0][0])[t] = 0;
+    if (t < 512) (&s.hist[0][0])[t] = 0;
     __syncthreads();
-    if (nans) atomicAdd(&s_nan, nans);
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
-        const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
+        const unsigned long long p0 = s.prefix[0], p1 = s.prefix[1];
         const bool same = p0 == p1;
+        auto count = [&](unsigned long long key) {
+            const unsigned long long hi = pass == 0 ? 0ull : (key >> (shift + 8));
+            const unsigned d = (unsigned)(key >> shift) & 255u;
+            if (hi == p0) atomicAdd(&s.hist[0][d], 1u);
+            if (!same && hi == p1) atomicAdd(&s.hist[1][d], 1u);
+        };
+        if (REG) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (valid[c]) {
-                const unsigned long long hi = pass == 0 ? 0ull : (k[c] >> (shift + 8));
-                const unsigned d = (unsigned)(k[c] >> shift) & 255u;
-                if (hi == p0) atomicAdd(&s_hist[0][d], 1u);
-                if (!same && hi == p1) atomicAdd(&s_hist[1][d], 1u);
+            for (int c = 0; c < 4; ++c)
+                if (valid[c]) count(k[c]);
+        } else {
+            constexpr int U = 8;
+            int64_t i = t;
+            for (; i + (U - 1) * 1024 < n; i += U * 1024) {
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = ld_narrow(x + i + u * 1024);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (pass == 0) nans += v[u] != v[u] ? 1u : 0u;
+                    count(key_of(v[u]));
+                }
             }
+            for (; i < n; i += 1024) {
+                const double v = ld_narrow(x + i);
+                if (pass == 0) nans += v != v ? 1u : 0u;
+                count(key_of(v));
+            }
+        }
+        if (pass == 0 && nans) atomicAdd(&s.nan, nans);
         __syncthreads();
         if (w < 2) {  // wave r finds the bin of rank r: four bins per lane, a scan over the wave
-            const unsigned *h = s_hist[(w == 1 && !same) ? 1 : 0];
+            const unsigned *h = s.hist[(w == 1 && !same) ? 1 : 0];
             unsigned c4[4], tot = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -273,30 +298,47 @@ __global__ __launch_bounds__(1024) void quantile_small_kernel(const double *__re
                 if (lane >= off) inc += v;
             }
             unsigned run = inc - tot;
-            const unsigned rank = s_rank[w];
+            const unsigned rank = s.rank[w];
             const unsigned long long pw = w == 0 ? p0 : p1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (rank >= run && rank < run + c4[i]) {  // exactly one (lane, i)
-                    s_prefix[w] = (pw << 8) | (unsigned long long)(lane * 4 + i);
-                    s_rank[w] = rank - run;
+                    s.prefix[w] = (pw << 8) | (unsigned long long)(lane * 4 + i);
+                    s.rank[w] = rank - run;
                 }
                 run += c4[i];
             }
         }
         __syncthreads();
-        if (t < 512) (&s_hist[0][0])[t] = 0;
+        if (t < 512) (&s.hist[0][0])[t] = 0;
         __syncthreads();
     }
-    if (t == 0) {
+}
+
+// torch's lerp between the two order statistics (at::native lerp: one fused multiply-add onto the nearer end)
+__device__ __forceinline__ double quantile_lerp(unsigned long long k0, unsigned long long k1, double w, bool any_nan)
+{
+    const double a = value_of(k0), b = value_of(k1), diff = b - a;
+    const double r = (fabs(w) < 0.5) ? fma(w, diff, a) : fma(w - 1.0, diff, b);
+    return any_nan ? __longlong_as_double(0x7ff8000000000000ll) : r;
+}
+
+// n <= QSMALL values: one launch instead of eight (the select of a task at the reference's default 4 096
+// environments).
+__global__ __launch_bounds__(1024) void quantile_small_kernel(const double *__restrict__ x, int n, double q,
+                                                              QuantileState *states, double *out)
+{
+    __shared__ BlockSelect s;
+    const double ranks = q * (double)(n - 1);
+    const long long below = (long long)ranks;  // toType(kLong): truncation
+    const long long above = (long long)ceil(ranks);
+    block_select<true>(x, n, below, above, s);
+    if (threadIdx.x == 0) {
         const double wgt = ranks - (double)below;
-        const double a = value_of(s_prefix[0]), b = value_of(s_prefix[1]);
-        const double diff = b - a;
-        double r = (fabs(wgt) < 0.5) ? fma(wgt, diff, a) : fma(wgt - 1.0, diff, b);
-        if (s_nan != 0) r = __longlong_as_double(0x7ff8000000000000ll);
+        const double r = quantile_lerp(s.prefix[0], s.prefix[1], wgt, s.nan != 0);
         QuantileState st;
-        st.prefix[0] = s_prefix[0];
-        st.prefix[1] = s_prefix[1];
+        st.prefix[0] = s.prefix[0];
+        st.prefix[1] = s.prefix[1];
         st.rank[0] = (unsigned long long)below;
         st.rank[1] = (unsigned long long)above;
         st.weight = wgt;
@@ -391,6 +433,7 @@ __global__ __launch_bounds__(256) void window_begin_kernel(WindowState *st, doub
 __global__ __launch_bounds__(1024) void window_hist_kernel(const double *__restrict__ x, int64_t n, WindowState *st)
 {
     __shared__ unsigned s_hist[WBINS];  // 64 KB
+    if (st->status != IGX_QW_REFINED) return;  // a round of the host-free sequence that the round before made unnecessary
     for (int i = threadIdx.x; i < WBINS; i += 1024) s_hist[i] = 0;
     const unsigned long long lo = st->lo;
     const unsigned shift = st->shift;
@@ -428,6 +471,7 @@ __global__ __launch_bounds__(1024) void window_locate_kernel(WindowState *st, un
     __shared__ unsigned s_bin, s_count, s_status;
     unsigned *hist = window_hist(st);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (st->status != IGX_QW_REFINED) return;  // already located (block-uniform: one block, read before any write)
     if (t == 0) {
         s_bin = WNONE;
         s_count = 0;
@@ -498,10 +542,12 @@ __global__ __launch_bounds__(1024) void window_locate_kernel(WindowState *st, un
         s.status = status;
         *st = s;
         s_status = status;
-        decision[0] = (long long)status;
-        decision[1] = status == IGX_QW_COLLECT ? (long long)c : 0ll;
-        decision[2] = (long long)b;
-        decision[3] = (long long)s.rounds;
+        if (decision) {
+            decision[0] = (long long)status;
+            decision[1] = status == IGX_QW_COLLECT ? (long long)c : 0ll;
+            decision[2] = (long long)b;
+            decision[3] = (long long)s.rounds;
+        }
     }
     __syncthreads();
     if (s_status == IGX_QW_REFINED) {
@@ -517,39 +563,72 @@ __global__ void window_slots_init_kernel(unsigned long long *slots)
     if (threadIdx.x == 1) slots[1] = ~0ull;
 }
 
-// slots = {number of this shard's keys in the located bin, smallest key of this shard above that bin, the keys}
-__global__ __launch_bounds__(256) void window_collect_kernel(const double *__restrict__ x, int64_t n, const WindowState *st,
-                                                             unsigned long long *slots, long long num_slots)
+// slots = {number of this shard's keys in the located bin, smallest key of this shard above that bin, the keys}.
+// Same-address atomics are what this kernel would otherwise spend its time on (one per candidate and one
+// minimum per wave, a few nanoseconds each, serialised): a workgroup gathers its candidates and its minimum in
+// LDS and goes to memory with one add and one min.
+__global__ __launch_bounds__(1024) void window_collect_kernel(const double *__restrict__ x, int64_t n, const WindowState *st,
+                                                              unsigned long long *slots, long long num_slots)
 {
+    __shared__ unsigned long long s_keys[IGX_QUANTILE_WINDOW_MAX_CANDIDATES];
+    __shared__ unsigned long long s_min, s_base;
+    __shared__ unsigned s_cnt;
     const unsigned long long lo = st->lo;
     const unsigned shift = st->shift, b0 = st->bin;
     const bool emit = st->status == IGX_QW_COLLECT;
+    if (!emit && st->status != IGX_QW_VALUE) return;  // host-free sequence: nothing was located, the fallback selects
+    if (threadIdx.x == 0) {
+        s_min = ~0ull;
+        s_cnt = 0;
+    }
+    __syncthreads();
     unsigned long long mn = ~0ull;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const unsigned long long k = key_of(ld_narrow(x + i));
+    auto take = [&](double v) {
+        const unsigned long long k = key_of(v);
         const unsigned b = window_bin(k, lo, shift);
         if (b == b0) {
-            if (emit) {
-                const unsigned long long pos = atomicAdd(&slots[0], 1ull);
-                if ((long long)pos + 2 < num_slots) slots[2 + pos] = k;
+            if (emit) {  // at most `capacity` keys of all shards together lie in the bin, so the LDS list cannot overflow
+                const unsigned pos = atomicAdd(&s_cnt, 1u);
+                if (pos < IGX_QUANTILE_WINDOW_MAX_CANDIDATES) s_keys[pos] = k;
             }
         } else if (b > b0) {
             mn = k < mn ? k : mn;
         }
+    };
+    // eight loads in flight per thread, as in the histogram kernels
+    constexpr int U = 8;
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld_narrow(x + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) take(v[u]);
     }
+    for (; i < n; i += stride) take(ld_narrow(x + i));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const unsigned long long o = __shfl_xor(mn, off);
         mn = o < mn ? o : mn;
     }
-    if ((threadIdx.x & 63) == 0 && mn != ~0ull) atomicMin(&slots[1], mn);
+    if ((threadIdx.x & 63) == 0 && mn != ~0ull) atomicMin(&s_min, mn);
+    __syncthreads();
+    const unsigned cnt = s_cnt < IGX_QUANTILE_WINDOW_MAX_CANDIDATES ? s_cnt : IGX_QUANTILE_WINDOW_MAX_CANDIDATES;
+    if (threadIdx.x == 0) {
+        if (s_min != ~0ull) atomicMin(&slots[1], s_min);
+        s_base = s_cnt ? atomicAdd(&slots[0], (unsigned long long)s_cnt) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    for (unsigned j = threadIdx.x; j < cnt; j += 1024)
+        if ((long long)(base + j) + 2 < num_slots) slots[2 + base + j] = s_keys[j];
 }
 
 // one block: sort the gathered keys of the located bin, pick the two order statistics, interpolate like
 // quantile_finish_kernel, centre the window on the value for the next call
 __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, const unsigned long long *__restrict__ g,
-                                                             int num_ranks, long long num_slots, double *out)
+                                                             int num_ranks, long long num_slots, double *out, int host_free)
 {
     __shared__ unsigned long long s_keys[IGX_QUANTILE_WINDOW_MAX_CANDIDATES];
     __shared__ unsigned s_off[IGX_QUANTILE_WINDOW_MAX_RANKS + 1];
@@ -557,6 +636,8 @@ __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, co
     __shared__ unsigned s_ok;
     const int t = threadIdx.x;
     const WindowState s = *st;
+    // host-free sequence: the rounds that were enqueued did not locate a small enough bin; window_fallback_kernel selects
+    if (host_free && s.status != IGX_QW_COLLECT && s.status != IGX_QW_VALUE) return;
     if (t == 0) {
         unsigned long long total = 0, mn = ~0ull;
         bool ok = s.status == IGX_QW_COLLECT || s.status == IGX_QW_VALUE;
@@ -617,6 +698,27 @@ __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, co
             n.lo = k0 > half ? k0 - half : 0ull;
         }
         *st = n;
+        if (out) *out = r;
+    }
+}
+
+// Last kernel of the host-free sequence: when the enqueued rounds did not resolve the quantile (a cold or outrun
+// window on data that needs more than two rounds, or more than 4 096 copies of the value) ONE workgroup runs the
+// whole select - slow (it streams the values eight times through one CU) but exact, and rare: the window the
+// rounds left behind is kept, so the next call continues from it.
+constexpr unsigned IGX_QW_FELL_BACK = 6;
+__global__ __launch_bounds__(1024) void window_fallback_kernel(const double *__restrict__ x, int64_t n, WindowState *st,
+                                                               double *out)
+{
+    __shared__ BlockSelect sel;
+    const WindowState w = *st;  // every thread reads before the barriers inside block_select; thread 0 writes after them
+    if (w.status == IGX_QW_COLLECT || w.status == IGX_QW_VALUE) return;
+    block_select<false>(x, n, (long long)w.rank[0], (long long)w.rank[1], sel);
+    if (threadIdx.x == 0) {
+        const double r = quantile_lerp(sel.prefix[0], sel.prefix[1], w.weight, sel.nan != 0);
+        st->result = r;
+        st->rounds = 0;
+        st->status = IGX_QW_FELL_BACK;
         if (out) *out = r;
     }
 }
@@ -741,9 +843,9 @@ extern "C" int igx_quantile_window_collect(const double *x, int64_t n, const voi
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned long long *sl = reinterpret_cast<unsigned long long *>(slots);
     hipLaunchKernelGGL(window_slots_init_kernel, dim3(1), dim3(64), 0, st, sl);
-    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
-    hipLaunchKernelGGL(window_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n,
+    int64_t blocks = (n + 1024 * 16 - 1) / (1024 * 16);
+    blocks = blocks < 1 ? 1 : blocks > 512 ? 512 : blocks;
+    hipLaunchKernelGGL(window_collect_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, x, n,
                        static_cast<const WindowState *>(workspace), sl, (long long)num_slots);
     return launch_status("igx_quantile_window_collect");
 }
@@ -762,6 +864,44 @@ extern "C" int igx_quantile_window_finish(void *workspace, const uint64_t *gathe
                     IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2);
     hipLaunchKernelGGL(window_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
                        static_cast<WindowState *>(workspace), reinterpret_cast<const unsigned long long *>(gathered),
-                       (int)num_ranks, (long long)num_slots, out);
+                       (int)num_ranks, (long long)num_slots, out, 0);
     return launch_status("igx_quantile_window_finish");
+}
+
+// layout of the host-free select inside a workspace of IGX_QUANTILE_WORKSPACE_BYTES: the 512-byte header of the
+// multi-pass select (its result field is where igx_ant_imitate_finish reads), the window state and histogram, the slots
+constexpr size_t HF_WINDOW = 512, HF_SLOTS = HF_WINDOW + IGX_QUANTILE_WINDOW_WORKSPACE_BYTES;
+constexpr long long HF_NUM_SLOTS = IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2;
+static_assert(HF_SLOTS % 16 == 0 && HF_SLOTS + 8 * HF_NUM_SLOTS <= IGX_QUANTILE_WORKSPACE_BYTES, "fits the select's workspace");
+
+extern "C" int igx_quantile_f64_windowed(const double *x, int64_t n, double q, double *out, void *workspace,
+                                         igx_stream_t stream)
+{
+    const char *who = "igx_quantile_f64_windowed";
+    if (!out) return fail(IGX_E_NULL, "%s: out is NULL", who);
+    if (n <= QSMALL || n >= (int64_t(1) << 31)) return igx_quantile_f64(x, n, q, out, workspace, stream);
+    int rc = check_ws(workspace, who);
+    if (rc != IGX_OK) return rc;
+    if (!x) return fail(IGX_E_NULL, "%s: x is NULL", who);
+    if (!(q >= 0.0 && q <= 1.0)) return fail(IGX_E_PARAM, "%s: q must lie in [0, 1]", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *base = static_cast<char *>(workspace);
+    WindowState *ws = reinterpret_cast<WindowState *>(base + HF_WINDOW);
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(base + HF_SLOTS);
+    static const int per_thread = tuning_int("IGX_QUANTILE_WINDOW_PER_THREAD", 16);
+    int64_t hb = (n + 1024 * (int64_t)per_thread - 1) / (1024 * (int64_t)per_thread);
+    hb = hb < 1 ? 1 : hb > 512 ? 512 : hb;
+    int64_t cb = (n + 1024 * 16 - 1) / (1024 * 16);
+    cb = cb < 1 ? 1 : cb > 512 ? 512 : cb;
+    hipLaunchKernelGGL(window_begin_kernel, dim3(8), dim3(256), 0, st, ws, q, (unsigned long long)n, 0);
+    for (int round = 0; round < 2; ++round) {  // the second round returns at once when the first one located the bin
+        hipLaunchKernelGGL(window_hist_kernel, dim3((unsigned)hb), dim3(1024), 0, st, x, n, ws);
+        hipLaunchKernelGGL(window_locate_kernel, dim3(1), dim3(1024), 0, st, ws,
+                           (unsigned)IGX_QUANTILE_WINDOW_MAX_CANDIDATES, static_cast<long long *>(nullptr));
+    }
+    hipLaunchKernelGGL(window_slots_init_kernel, dim3(1), dim3(64), 0, st, slots);
+    hipLaunchKernelGGL(window_collect_kernel, dim3((unsigned)cb), dim3(1024), 0, st, x, n, ws, slots, HF_NUM_SLOTS);
+    hipLaunchKernelGGL(window_finish_kernel, dim3(1), dim3(1024), 0, st, ws, slots, 1, HF_NUM_SLOTS, out, 1);
+    hipLaunchKernelGGL(window_fallback_kernel, dim3(1), dim3(1024), 0, st, x, n, ws, out);
+    return launch_status(who);
 }

@@ -460,6 +460,21 @@ def quantile_f64(x, q, workspace=None):
     return out
 
 
+def quantile_f64_windowed(x, q, workspace):
+    """The same value as quantile_f64 through igx_quantile_f64_windowed: fewer launches when the same workspace is
+    used call after call on data that drifts (the window the select keeps there follows the value); returns a 0-dim
+    tensor."""
+    if workspace.numel() * workspace.element_size() < _abi.IGX_QUANTILE_WORKSPACE_BYTES:
+        raise ValueError("workspace smaller than IGX_QUANTILE_WORKSPACE_BYTES")
+    dev = x.device
+    out = torch.empty((), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_quantile_f64_windowed(_lib.tensor_ptr(x, torch.float64), C.c_int64(x.numel()), C.c_double(q),
+                                                  _lib.tensor_ptr(out), _lib.tensor_ptr(workspace), _lib.current_stream(dev))
+    _lib.check(rc)
+    return out
+
+
 def quantile_sharded(x, q, n_total, workspace, all_reduce):
     """The same select over the shards of a multi-GPU job: `all_reduce(hist)` must sum the int64 histogram
     tensor over the ranks in place (torch.distributed.all_reduce).  The result is left in the workspace

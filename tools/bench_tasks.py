@@ -102,6 +102,9 @@ def main():
         report("ant_imitate_step(total)", timed(lambda i: ops.ant_imitate_step(p, sets[i % 3], im, n), a.steps), 556 + 32)
         report("ant_imitate_observe", timed(lambda i: ops.ant_imitate_observe(p, sets[i % 3], im, n), a.steps), 556 + 24)
         report("quantile_f64", timed(lambda i: ops.quantile_f64(pd, 0.99, ws), a.steps), 8 * 6)
+        ws_w = torch.zeros_like(ws)
+        report("quantile_f64_windowed", timed(lambda i: ops.quantile_f64_windowed(pd, 0.99, ws_w), a.steps), 8 * 2)
+        assert float(ops.quantile_f64_windowed(pd, 0.99, ws_w)) == float(ops.quantile_f64(pd, 0.99, ws)), "windowed select differs"
         # the two-collective form on one rank (identity collectives): kernels alone, and the whole protocol with
         # the host's read of the decision between the all-reduce and the gather
         wq = ops.WindowQuantile(DEV)
