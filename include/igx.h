@@ -227,7 +227,7 @@ int igx_quantile_f64(const double *x, int64_t n, double q, double *out, void *wo
  * does every step): the window select of igx_quantile_window_* below on one GPU with no host decision in between - two
  * histogram rounds are enqueued (the second returns at once when the first located a bin of at most 4 096 keys), then
  * collect, sort and interpolate; when that does not resolve the value (a first call on narrow data, more than 4 096
- * copies of the value) a last kernel runs the whole select in ONE workgroup: exact, but about 0.5 ms per 2^20 values.
+ * copies of the value) the last kernel runs the whole select in ONE workgroup: exact, but about 0.5 ms per 2^20 values.
  * The window lives in `workspace` (same size as above) between calls; any contents are a valid start.  The bits are
  * those of igx_quantile_f64.  n <= 4096 and n >= 2^31 take igx_quantile_f64. */
 int igx_quantile_f64_windowed(const double *x, int64_t n, double q, double *out, void *workspace, igx_stream_t stream);

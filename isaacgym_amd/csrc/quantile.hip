@@ -361,6 +361,7 @@ constexpr unsigned WMAGIC = 0x51574e44u;
 constexpr unsigned WSHIFT_MAX = 50;  // (WBINS - 2) << 50 still fits 64 bits
 constexpr unsigned WNONE = 0xffffffffu;
 constexpr unsigned IGX_QW_BAD_GATHER = 5;
+constexpr unsigned IGX_QW_FELL_BACK = 6;  // host-free sequence: the value came from the one-workgroup select
 
 struct WindowState {  // the first 128 bytes of the workspace
     unsigned long long lo;
@@ -398,9 +399,11 @@ __device__ __forceinline__ unsigned shift_for_span(unsigned long long span)
     return s;
 }
 
-__global__ __launch_bounds__(256) void window_begin_kernel(WindowState *st, double q, unsigned long long n_total, int reset)
+__global__ __launch_bounds__(256) void window_begin_kernel(WindowState *st, double q, unsigned long long n_total, int reset,
+                                                           unsigned long long *slots)
 {
     unsigned *hist = window_hist(st);
+    if (slots && blockIdx.x == 0 && threadIdx.x < 2) slots[threadIdx.x] = threadIdx.x == 0 ? 0ull : ~0ull;  // count, minimum
     for (int i = blockIdx.x * 256 + threadIdx.x; i < IGX_QUANTILE_WINDOW_HIST_WORDS; i += gridDim.x * 256) hist[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         WindowState s = *st;
@@ -628,7 +631,8 @@ __global__ __launch_bounds__(1024) void window_collect_kernel(const double *__re
 // one block: sort the gathered keys of the located bin, pick the two order statistics, interpolate like
 // quantile_finish_kernel, centre the window on the value for the next call
 __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, const unsigned long long *__restrict__ g,
-                                                             int num_ranks, long long num_slots, double *out, int host_free)
+                                                             int num_ranks, long long num_slots, double *out,
+                                                             const double *__restrict__ x, int64_t n)
 {
     __shared__ unsigned long long s_keys[IGX_QUANTILE_WINDOW_MAX_CANDIDATES];
     __shared__ unsigned s_off[IGX_QUANTILE_WINDOW_MAX_RANKS + 1];
@@ -636,8 +640,22 @@ __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, co
     __shared__ unsigned s_ok;
     const int t = threadIdx.x;
     const WindowState s = *st;
-    // host-free sequence: the rounds that were enqueued did not locate a small enough bin; window_fallback_kernel selects
-    if (host_free && s.status != IGX_QW_COLLECT && s.status != IGX_QW_VALUE) return;
+    // host-free sequence (x given): the rounds that were enqueued did not resolve the value (a cold or outrun window
+    // on data that needs more than two rounds, or more than 4 096 copies of the value) - this workgroup runs the whole
+    // select itself: slow (it streams the values eight times through one CU) but exact, and rare: the window the
+    // rounds left behind is kept, so the next call continues from it.
+    if (x && s.status != IGX_QW_COLLECT && s.status != IGX_QW_VALUE) {
+        __shared__ BlockSelect sel;
+        block_select<false>(x, n, (long long)s.rank[0], (long long)s.rank[1], sel);
+        if (t == 0) {
+            const double r = quantile_lerp(sel.prefix[0], sel.prefix[1], s.weight, sel.nan != 0);
+            st->result = r;
+            st->rounds = 0;
+            st->status = IGX_QW_FELL_BACK;
+            if (out) *out = r;
+        }
+        return;
+    }
     if (t == 0) {
         unsigned long long total = 0, mn = ~0ull;
         bool ok = s.status == IGX_QW_COLLECT || s.status == IGX_QW_VALUE;
@@ -698,27 +716,6 @@ __global__ __launch_bounds__(1024) void window_finish_kernel(WindowState *st, co
             n.lo = k0 > half ? k0 - half : 0ull;
         }
         *st = n;
-        if (out) *out = r;
-    }
-}
-
-// Last kernel of the host-free sequence: when the enqueued rounds did not resolve the quantile (a cold or outrun
-// window on data that needs more than two rounds, or more than 4 096 copies of the value) ONE workgroup runs the
-// whole select - slow (it streams the values eight times through one CU) but exact, and rare: the window the
-// rounds left behind is kept, so the next call continues from it.
-constexpr unsigned IGX_QW_FELL_BACK = 6;
-__global__ __launch_bounds__(1024) void window_fallback_kernel(const double *__restrict__ x, int64_t n, WindowState *st,
-                                                               double *out)
-{
-    __shared__ BlockSelect sel;
-    const WindowState w = *st;  // every thread reads before the barriers inside block_select; thread 0 writes after them
-    if (w.status == IGX_QW_COLLECT || w.status == IGX_QW_VALUE) return;
-    block_select<false>(x, n, (long long)w.rank[0], (long long)w.rank[1], sel);
-    if (threadIdx.x == 0) {
-        const double r = quantile_lerp(sel.prefix[0], sel.prefix[1], w.weight, sel.nan != 0);
-        st->result = r;
-        st->rounds = 0;
-        st->status = IGX_QW_FELL_BACK;
         if (out) *out = r;
     }
 }
@@ -798,7 +795,8 @@ extern "C" int igx_quantile_window_begin(void *workspace, double q, int64_t n_to
     if (n_total <= 0 || n_total >= (int64_t(1) << 31))
         return fail(IGX_E_SIZE, "igx_quantile_window_begin: n_total must lie in [1, 2^31)");
     hipLaunchKernelGGL(window_begin_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<WindowState *>(workspace), q, (unsigned long long)n_total, (int)reset_window);
+                       static_cast<WindowState *>(workspace), q, (unsigned long long)n_total, (int)reset_window,
+                       static_cast<unsigned long long *>(nullptr));
     return launch_status("igx_quantile_window_begin");
 }
 
@@ -864,7 +862,7 @@ extern "C" int igx_quantile_window_finish(void *workspace, const uint64_t *gathe
                     IGX_QUANTILE_WINDOW_MAX_CANDIDATES + 2);
     hipLaunchKernelGGL(window_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
                        static_cast<WindowState *>(workspace), reinterpret_cast<const unsigned long long *>(gathered),
-                       (int)num_ranks, (long long)num_slots, out, 0);
+                       (int)num_ranks, (long long)num_slots, out, static_cast<const double *>(nullptr), (int64_t)0);
     return launch_status("igx_quantile_window_finish");
 }
 
@@ -893,15 +891,13 @@ extern "C" int igx_quantile_f64_windowed(const double *x, int64_t n, double q, d
     hb = hb < 1 ? 1 : hb > 512 ? 512 : hb;
     int64_t cb = (n + 1024 * 16 - 1) / (1024 * 16);
     cb = cb < 1 ? 1 : cb > 512 ? 512 : cb;
-    hipLaunchKernelGGL(window_begin_kernel, dim3(8), dim3(256), 0, st, ws, q, (unsigned long long)n, 0);
+    hipLaunchKernelGGL(window_begin_kernel, dim3(8), dim3(256), 0, st, ws, q, (unsigned long long)n, 0, slots);
     for (int round = 0; round < 2; ++round) {  // the second round returns at once when the first one located the bin
         hipLaunchKernelGGL(window_hist_kernel, dim3((unsigned)hb), dim3(1024), 0, st, x, n, ws);
         hipLaunchKernelGGL(window_locate_kernel, dim3(1), dim3(1024), 0, st, ws,
                            (unsigned)IGX_QUANTILE_WINDOW_MAX_CANDIDATES, static_cast<long long *>(nullptr));
     }
-    hipLaunchKernelGGL(window_slots_init_kernel, dim3(1), dim3(64), 0, st, slots);
     hipLaunchKernelGGL(window_collect_kernel, dim3((unsigned)cb), dim3(1024), 0, st, x, n, ws, slots, HF_NUM_SLOTS);
-    hipLaunchKernelGGL(window_finish_kernel, dim3(1), dim3(1024), 0, st, ws, slots, 1, HF_NUM_SLOTS, out, 1);
-    hipLaunchKernelGGL(window_fallback_kernel, dim3(1), dim3(1024), 0, st, x, n, ws, out);
+    hipLaunchKernelGGL(window_finish_kernel, dim3(1), dim3(1024), 0, st, ws, slots, 1, HF_NUM_SLOTS, out, x, n);
     return launch_status(who);
 }
