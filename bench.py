@@ -198,6 +198,9 @@ def main():
                   "heading_vec", "rew"):
             s[k] = sets[0][k]
 
+    # the tasks' own calling convention: one validated argument struct per buffer set, reused from step to step
+    caches = [dict() for _ in sets]
+
     es = None
     if args.episode_stats:
         from isaacgym_amd.episode_stats import EpisodeStats
@@ -211,11 +214,11 @@ def main():
             if es is not None and timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                step(p, sets[i % NUM_INPUT_SETS], n)
+                step(p, sets[i % NUM_INPUT_SETS], n, caches[i % NUM_INPUT_SETS])
                 e1.record()
                 step_events.append((e0, e1))
             else:
-                step(p, sets[i % NUM_INPUT_SETS], n)
+                step(p, sets[i % NUM_INPUT_SETS], n, caches[i % NUM_INPUT_SETS])
             if es is not None:
                 es.step(sets[0]["rew"], sets[0]["reset"])
 
