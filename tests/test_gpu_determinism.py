@@ -109,3 +109,42 @@ def test_selects_and_statistics_repeat_bit_for_bit():
             es.step(rew, done)
         totals.add(tuple(es.totals()))
     assert len(totals) == 1
+
+
+def test_calls_on_two_streams_do_not_share_state():
+    """The library is re-entrant: the same entry points running concurrently on two streams (own buffers, own
+    workspaces) leave what the same calls leave one after the other."""
+    n = 60001
+    pa = synthetic.loco_params(synthetic.ANT, seed=3, rng_offset=4)
+    ph = synthetic.allegro_params("full_state", seed=5, rng_offset=6)
+    a0, h0 = synthetic.loco_state(synthetic.ANT, n, 2, DEV), synthetic.allegro_state(n, 3, DEV, "full_state")
+    a0["reset"][::5] = 1
+    h0["reset"][::4] = 1
+    x = torch.randn(n, device=DEV, dtype=torch.float64)
+
+    def work(a, h, ws):
+        for _ in range(3):
+            ops.ant_step(pa, a, n)
+            ops.allegro_post_physics(ph, h, n)
+            q = ops.quantile_f64_windowed(x, 0.9, ws)
+        return q
+
+    serial = [(_clone(a0), _clone(h0), torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV))
+              for _ in range(2)]
+    qs = [work(*s) for s in serial]
+    torch.cuda.synchronize()
+    conc = [(_clone(a0), _clone(h0), torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV))
+            for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    qc = []
+    for st, c in zip(streams, conc):
+        st.wait_stream(torch.cuda.current_stream())
+    for rep in range(1):
+        for st, c in zip(streams, conc):
+            with torch.cuda.stream(st):
+                qc.append(work(*c))
+    torch.cuda.synchronize()
+    for s, c, q1, q2 in zip(serial, conc, qs, qc):
+        _same(s[0], c[0], "ant on a side stream")
+        _same(s[1], c[1], "allegro on a side stream")
+        assert float(q1) == float(q2) == float(torch.quantile(x.cpu(), 0.9))
