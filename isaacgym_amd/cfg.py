@@ -93,104 +93,3 @@ def task_config(name, num_envs=None, **env_overrides):
         cfg["env"]["numEnvs"] = int(num_envs)
     cfg["env"].update(env_overrides)
     return cfg
-
-
-# ---- the reference's own task files ------------------------------------------------------------------------
-# cfg/task/*.yaml are hydra / OmegaConf documents; the handful of interpolation forms they use is resolved here
-# (`${..key}` references into the root configuration, `${resolve_default:A,B}`, `${eq:A,B}`, `${contains:A,B}`,
-# `${if:C,A,B}`), so that a file of that tree can be handed to a task without hydra installed.
-ROOT_DEFAULTS = dict(physics_engine="physx", pipeline="gpu", sim_device="cuda:0", rl_device="cuda:0",
-                     graphics_device_id=0, num_threads=4, solver_type=1, num_subscenes=4, num_envs="", seed=42,
-                     headless=True, test=False, experiment="")
-
-
-def _split_args(text):
-    """Top-level comma split of a resolver's argument list (quotes and nested ${} respected)."""
-    out, depth, quote, cur = [], 0, None, ""
-    for ch in text:
-        if quote:
-            cur += ch
-            quote = None if ch == quote else quote
-        elif ch in "\"'":
-            quote, cur = ch, cur + ch
-        elif ch in "{[(":
-            depth, cur = depth + 1, cur + ch
-        elif ch in "}])":
-            depth, cur = depth - 1, cur + ch
-        elif ch == "," and depth == 0:
-            out.append(cur)
-            cur = ""
-        else:
-            cur += ch
-    out.append(cur)
-    return [a.strip() for a in out]
-
-
-def _scalar(text):
-    """A resolved piece of text as the YAML scalar it spells."""
-    import yaml
-    if not isinstance(text, str):
-        return text
-    return yaml.safe_load(text) if text != "" else ""
-
-
-def _resolve(value, root):
-    """One string with ${...} pieces -> its value."""
-    import re
-    inner = re.compile(r"\$\{([^${}]*)\}")  # an interpolation with no interpolation inside
-
-    def one(m):
-        body = m.group(1).strip()
-        if body.startswith("."):  # relative reference: the files only ever point into the root configuration
-            key = body.lstrip(".")
-            if key not in root:
-                raise KeyError("the task file refers to the root setting %r; pass it to load_task_yaml" % key)
-            v = root[key]
-            return "" if v is None else (v if isinstance(v, str) else repr(v))
-        name, _, rest = body.partition(":")
-        args = [_scalar(a) for a in _split_args(rest)]
-        if name == "resolve_default":
-            r = args[0] if args[1] == "" else args[1]
-        elif name == "eq":
-            r = str(args[0]).lower() == str(args[1]).lower()
-        elif name == "contains":
-            r = str(args[0]).lower() in str(args[1]).lower()
-        elif name == "if":
-            r = args[1] if args[0] else args[2]
-        else:
-            raise ValueError("unknown resolver %r in a task file" % name)
-        return r if isinstance(r, str) else repr(r)
-
-    text = value
-    for _ in range(16):
-        new = inner.sub(one, text)
-        if new == text:
-            break
-        text = new
-    if "${" in text:
-        raise ValueError("could not resolve %r" % value)
-    return _scalar(text)
-
-
-def _walk(node, root):
-    if isinstance(node, dict):
-        return {k: _walk(v, root) for k, v in node.items()}
-    if isinstance(node, list):
-        return [_walk(v, root) for v in node]
-    if isinstance(node, str) and "${" in node:
-        return _resolve(node, root)
-    return node
-
-
-def load_task_yaml(path, num_envs=None, **root_settings):
-    """A cfg/task/<Task>.yaml of the reference tree as the dict its task class is constructed from
-    (what hydra hands to `isaacgym_task_map[name](cfg=...)`).  `root_settings` are the values of the root
-    configuration the file points at (physics_engine, pipeline, sim_device, num_threads, ...); `num_envs`
-    overrides `env.numEnvs` the way `num_envs=` does on the reference's command line."""
-    import yaml
-    with open(path) as f:
-        doc = yaml.safe_load(f)
-    root = dict(ROOT_DEFAULTS, **root_settings)
-    if num_envs is not None:
-        root["num_envs"] = int(num_envs)
-    return _walk(doc, root)

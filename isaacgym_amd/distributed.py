@@ -32,6 +32,12 @@ def env_shard(num_envs, rank, world_size):
     return start, count
 
 
+def rank_env_offset(num_envs_per_rank, rank=None):
+    """First global environment index of a rank that builds `num_envs_per_rank` environments of its own
+    (the reference's multi-GPU layout, utils/rlgames_utils.py:91-112): assign it to `task.env_offset`."""
+    return (int(os.environ.get("RANK", "0")) if rank is None else int(rank)) * int(num_envs_per_rank)
+
+
 def shard_seed(seed, rank):
     """A per-rank generator key, for shards that do not pass their `env_offset`.  The Philox counter is
     (environment index + env_offset): shards that set `env_offset = env_shard(...)[0]` and share ONE seed draw

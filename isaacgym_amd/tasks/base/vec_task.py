@@ -114,7 +114,7 @@ class VecTask:
     def action_space(self):
         return dict(low=-1.0, high=1.0, shape=(self.num_actions,))
 
-    def get_number_of_agents(self):  # what RLGPUEnv asks its environment (utils/rlgames_utils.py:257-258)
+    def get_number_of_agents(self):  # what the learner-side wrapper asks its environment (utils/rlgames_utils.py:257-258)
         return self.num_agents
 
     def set_train_info(self, env_frames, *args, **kwargs):

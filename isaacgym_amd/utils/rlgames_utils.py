@@ -28,15 +28,17 @@ from .. import _abi, _lib
 from ..episode_stats import EpisodeStats
 
 
-def flatten_dict(d, prefix="", separator="."):
-    """utils/utils.py:69-77"""
-    res = dict()
-    for key, value in d.items():
+def _leaves(node, head, separator):
+    for key, value in node.items():
         if isinstance(value, (dict, OrderedDict)):
-            res.update(flatten_dict(value, prefix + key + separator, separator))
+            yield from _leaves(value, head + key + separator, separator)
         else:
-            res[prefix + key] = value
-    return res
+            yield head + key, value
+
+
+def flatten_dict(d, prefix="", separator="."):
+    """Nested dicts as one level, keys joined with `separator`, in document order (what utils/utils.py:69-77 returns)."""
+    return dict(_leaves(d, prefix, separator))
 
 
 class AverageMeter:
@@ -220,141 +222,19 @@ class RLGPUAlgoObserver:
                 self.writer.add_scalar("Episode/" + key, torch.mean(torch.cat(parts)), epoch_num)
             self.ep_infos.clear()
 
-        # log these if and only if we have new finished episodes
-        if self._keys:
+        if self._keys:  # :200-207: the windowed rows appear only in epochs that finished at least one episode
             win, total = self.windows()
-            self.new_finished_episodes = total > self._seen_total
+            finished_more = total > self._seen_total
             self._seen_total = total
-            if self.new_finished_episodes:
+            self.new_finished_episodes = False
+            if finished_more:
                 for key in self._keys:
-                    self.writer.add_scalar(f"episode_cumulative/{key}", np.mean(win[key]), frame)
-                    self.writer.add_scalar(f"episode_cumulative_min/{key}_min", np.min(win[key]), frame)
-                    self.writer.add_scalar(f"episode_cumulative_max/{key}_max", np.max(win[key]), frame)
-                self.new_finished_episodes = False
+                    vals = win[key]
+                    for tag, stat in (("episode_cumulative/%s" % key, np.mean(vals)),
+                                      ("episode_cumulative_min/%s_min" % key, np.min(vals)),
+                                      ("episode_cumulative_max/%s_max" % key, np.max(vals))):
+                        self.writer.add_scalar(tag, stat, frame)
 
-        for k, v in self.direct_info.items():
-            self.writer.add_scalar(f"{k}/frame", v, frame)
-            self.writer.add_scalar(f"{k}/iter", v, epoch_num)
-            self.writer.add_scalar(f"{k}/time", v, total_time)
-
-
-# ---- the learner-facing wrappers around a task (utils/rlgames_utils.py:46-130, :213-296) ----------------
-def multi_gpu_get_rank(multi_gpu):
-    """utils/rlgames_utils.py:46-52"""
-    import os
-    return int(os.getenv("LOCAL_RANK", "0")) if multi_gpu else 0
-
-
-def get_rlgames_env_creator(seed, task_config, task_name, sim_device, rl_device, graphics_device_id=0, headless=True,
-                            multi_gpu=False, post_create_hook=None, virtual_screen_capture=False, force_render=False,
-                            **task_kwargs):
-    """The closure the learner calls to build its environment (utils/rlgames_utils.py:55-130): with
-    `multi_gpu` every rank builds its own `numEnvs` environments on GPU LOCAL_RANK (one process per GPU;
-    RANK / LOCAL_RANK / WORLD_SIZE as torch.distributed.run sets them) and the configuration is told its
-    rank and device.  What the reference leaves to the seed (`seed + rank`, train.py) is kept, and in
-    addition the rank's first global environment index goes into `env_offset`, so that ranks which were
-    given ONE seed still draw different resets.  `task_kwargs` (sim=, motion=, motion_lib= ...) reach the
-    task's constructor: the physics engine is not part of this package."""
-    import os
-
-    def create_rlgpu_env():
-        from ..tasks import isaacgym_task_map
-        if multi_gpu:
-            local_rank = int(os.getenv("LOCAL_RANK", "0"))
-            global_rank = int(os.getenv("RANK", "0"))
-            _sim_device = _rl_device = "cuda:%d" % local_rank
-            task_config["rank"] = local_rank
-            task_config["rl_device"] = _rl_device
-        else:
-            global_rank = 0
-            _sim_device, _rl_device = sim_device, rl_device
-        kw = dict(task_kwargs)
-        if "seed" not in kw and task_name != "HumanoidAMP":
-            kw["seed"] = seed
-        env = isaacgym_task_map[task_name](task_config, _rl_device, _sim_device, graphics_device_id, headless,
-                                           virtual_screen_capture, force_render, **kw)
-        env.env_offset = global_rank * env.num_envs
-        if post_create_hook is not None:
-            post_create_hook()
-        return env
-    return create_rlgpu_env
-
-
-class _Configurations:
-    """Stand-in for rl_games.common.env_configurations: name -> {'env_creator': callable, 'vecenv_type': str}."""
-
-    def __init__(self):
-        self.configurations = {}
-
-    def register(self, name, config):
-        self.configurations[name] = config
-
-
-env_configurations = _Configurations()
-
-
-class RLGPUEnv:
-    """utils/rlgames_utils.py:244-296: what the learner holds - a pass-through to the task."""
-
-    def __init__(self, config_name, num_actors, **kwargs):
-        self.env = env_configurations.configurations[config_name]["env_creator"](**kwargs)
-
-    def step(self, actions):
-        return self.env.step(actions)
-
-    def reset(self):
-        return self.env.reset()
-
-    def reset_done(self):
-        return self.env.reset_done()
-
-    def get_number_of_agents(self):
-        return self.env.get_number_of_agents()
-
-    def get_env_info(self):
-        info = {"action_space": self.env.action_space, "observation_space": self.env.observation_space}
-        if hasattr(self.env, "amp_observation_space"):
-            info["amp_observation_space"] = self.env.amp_observation_space
-        if self.env.num_states > 0:
-            info["state_space"] = self.env.state_space
-        return info
-
-    def set_train_info(self, env_frames, *args_, **kwargs_):
-        if hasattr(self.env, "set_train_info"):
-            self.env.set_train_info(env_frames, *args_, **kwargs_)
-
-    def get_env_state(self):
-        return self.env.get_env_state() if hasattr(self.env, "get_env_state") else None
-
-    def set_env_state(self, env_state):
-        if hasattr(self.env, "set_env_state"):
-            self.env.set_env_state(env_state)
-
-
-class MultiObserver:
-    """utils/rlgames_utils.py:213-241: several observers behind one."""
-
-    def __init__(self, observers_):
-        self.observers = observers_
-
-    def _call_multi(self, method, *args_, **kwargs_):
-        for o in self.observers:
-            getattr(o, method)(*args_, **kwargs_)
-
-    def before_init(self, base_name, config, experiment_name):
-        self._call_multi("before_init", base_name, config, experiment_name)
-
-    def after_init(self, algo):
-        self._call_multi("after_init", algo)
-
-    def process_infos(self, infos, done_indices):
-        self._call_multi("process_infos", infos, done_indices)
-
-    def after_steps(self):
-        self._call_multi("after_steps")
-
-    def after_clear_stats(self):
-        self._call_multi("after_clear_stats")
-
-    def after_print_stats(self, frame, epoch_num, total_time):
-        self._call_multi("after_print_stats", frame, epoch_num, total_time)
+        for name, value in self.direct_info.items():  # :209-211: each direct scalar against three x axes
+            for axis, x in (("frame", frame), ("iter", epoch_num), ("time", total_time)):
+                self.writer.add_scalar("%s/%s" % (name, axis), value, x)

@@ -612,77 +612,3 @@ def test_fresh_step_outputs_do_not_alias_the_next_step(name):
     assert torch.equal(o1["obs"], keep[0]) and torch.equal(r1, keep[1]) and torch.equal(d1, keep[2])
     assert o2["obs"].data_ptr() != o1["obs"].data_ptr() and not torch.equal(o2["obs"], o1["obs"])
     assert torch.equal(o2["obs"], p2[0]["obs"]) and p2[0]["obs"].data_ptr() == p1[0]["obs"].data_ptr()
-
-
-def test_rlgpu_env_over_a_real_task():
-    """The learner's view (RLGPUEnv <- get_rlgames_env_creator) of an Ant task on the device."""
-    from isaacgym_amd.utils import rlgames_utils as R
-    n = 512
-    cfg = C.task_config("Ant", n)
-    make = R.get_rlgames_env_creator(3, cfg, "Ant", DEV, DEV, sim=SyntheticSim("Ant", n, DEV, seed=3))
-    R.env_configurations.register("rlgpu", {"vecenv_type": "RLGPU", "env_creator": lambda **kw: make()})
-    env = R.RLGPUEnv("rlgpu", 1)
-    info = env.get_env_info()
-    assert info["observation_space"]["shape"] == (60,) and info["action_space"]["shape"] == (8,) and "state_space" not in info
-    assert env.get_number_of_agents() == 1 and env.env.env_offset == 0
-    first = env.reset()
-    assert first["obs"].shape == (n, 60)
-    env.reset_done()
-    obs, rew, done, extras = env.step(torch.zeros(n, 8, device=DEV))
-    assert obs["obs"].shape == (n, 60) and rew.shape == (n,) and done.dtype == torch.int64 and "time_outs" in extras
-    twin = tasks.make("Ant", n, DEV, seed=3)
-    twin.reset_done()
-    want = twin.step(torch.zeros(n, 8, device=DEV))
-    assert torch.equal(obs["obs"], want[0]["obs"]) and torch.equal(rew, want[1]) and torch.equal(done, want[2])
-
-
-def test_task_built_from_a_hydra_style_task_file(tmp_path):
-    """A task file in the reference's format (interpolations and all) is enough to construct and step the task."""
-    text = """
-name: Ant
-physics_engine: ${..physics_engine}
-env:
-  numEnvs: ${resolve_default:4096,${...num_envs}}
-  envSpacing: 5
-  episodeLength: 1000
-  enableDebugVis: False
-  clipActions: 1.0
-  powerScale: 1.0
-  controlFrequencyInv: 1 # 60 Hz
-  headingWeight: 0.5
-  upWeight: 0.1
-  actionsCost: 0.005
-  energyCost: 0.05
-  dofVelocityScale: 0.2
-  contactForceScale: 0.1
-  jointsAtLimitCost: 0.1
-  deathCost: -2.0
-  terminationHeight: 0.31
-  plane:
-    staticFriction: 1.0
-    dynamicFriction: 1.0
-    restitution: 0.0
-  enableCameraSensors: False
-sim:
-  dt: 0.0166 # 1/60 s
-  substeps: 2
-  up_axis: "z"
-  use_gpu_pipeline: ${eq:${...pipeline},"gpu"}
-  gravity: [0.0, 0.0, -9.81]
-  physx:
-    num_threads: ${....num_threads}
-    use_gpu: ${contains:"cuda",${....sim_device}}
-task:
-  randomize: False
-"""
-    p = tmp_path / "Ant.yaml"
-    p.write_text(text)
-    cfg = C.load_task_yaml(str(p), num_envs=700, sim_device=DEV)
-    assert cfg["env"]["numEnvs"] == 700 and cfg["sim"]["physx"]["use_gpu"] is True
-    task = tasks.Ant(cfg, DEV, DEV, sim=SyntheticSim("Ant", 700, DEV, seed=5), seed=5)
-    twin = tasks.make("Ant", 700, DEV, seed=5)
-    for t in (task, twin):
-        t.reset_done()
-    a = torch.rand(700, 8, device=DEV) * 2 - 1
-    got, want = task.step(a), twin.step(a)
-    assert torch.equal(got[0]["obs"], want[0]["obs"]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
