@@ -91,13 +91,22 @@ __device__ __forceinline__ f3 quat_rotate(f4 q, f3 v)
 
 #define IGX_TWO_PI_F 6.2831855f
 
-// torch.remainder(x, float32(2*pi)) for an x that came out of atan2: |x| <= pi,
-// so fmod(x, 2*pi) is x itself and only the sign fix-up of remainder is left
-// (-0.0 stays -0.0, NaN stays NaN, exactly as fmod-then-fix-up gives)
-__device__ __forceinline__ float remainder_2pi(float x)
+// torch.remainder(atan2(y, x), float32(2*pi)).  |atan2| <= pi, so fmod leaves the value alone and what is
+// left of remainder is its sign fix-up: add 2*pi to a negative non-zero value.  Whether atan2(y, x) is
+// negative is decided on the NUMERATOR, which is plain IEEE arithmetic and therefore bit-identical to the
+// reference's: the result is negative exactly when y < 0 (y = -0 gives -0, which remainder leaves alone, or
+// -pi behind a negative / negative-zero x).  Deciding on the library's atan2 result instead would let a
+// tiny negative quotient that it rounds or flushes to -0 lose its 2*pi: an observation error of 6.28.
+// NaN stays NaN.
+__device__ __forceinline__ float atan2_mod_2pi(float y, float x)
 {
-    return (x < 0.0f) ? x + IGX_TWO_PI_F : x;
+    const float a = atan2f(y, x);
+    const bool negative = (y < 0.0f) || (y == 0.0f && __builtin_signbit(y) && __builtin_signbit(x));
+    return negative ? a + IGX_TWO_PI_F : a;
 }
+
+// the same for asin(s) (the pitch of get_euler_xyz): negative exactly when s < 0
+__device__ __forceinline__ float mod_2pi_signed_by(float a, float s) { return (s < 0.0f) ? a + IGX_TWO_PI_F : a; }
 
 // :126-128
 __device__ __forceinline__ float normalize_angle(float x) { return atan2f(sinf(x), cosf(x)); }
@@ -109,8 +118,8 @@ __device__ __forceinline__ void euler_roll_yaw(f4 q, float &roll, float &yaw)
     float cosr_cosp = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
     float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
     float cosy_cosp = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
-    roll = remainder_2pi(atan2f(sinr_cosp, cosr_cosp));
-    yaw = remainder_2pi(atan2f(siny_cosp, cosy_cosp));
+    roll = atan2_mod_2pi(sinr_cosp, cosr_cosp);
+    yaw = atan2_mod_2pi(siny_cosp, cosy_cosp);
 }
 
 // :239-241 unscale
@@ -222,7 +231,7 @@ __device__ __forceinline__ float euler_pitch(f4 q)
 {
     const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
     const float pitch = (fabsf(sinp) >= 1.0f) ? copysign_sign(1.5707964f, sinp) : asinf(sinp);
-    return remainder_2pi(pitch);
+    return mod_2pi_signed_by(pitch, sinp);
 }
 
 // :198-212 quat_from_euler_xyz

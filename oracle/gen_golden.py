@@ -1944,7 +1944,88 @@ def gen_observer(seed=41, N=333, H=5, EPOCHS=4, G=48):
           "rows", [len(w) for w in writes])
 
 
-GENERATORS = {"observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+def gen_angles_edge(seed=81, n=2560):
+    """Torso rotations where the numerators of the roll / yaw atan2 of get_euler_xyz, 2(wx+yz) and 2(wz+xy), are
+    zero, signed zero, subnormal or at rounding-noise level, of both signs: `remainder(atan2(.), 2 pi)` maps a
+    numerator of -1e-9 to 6.2831855 and +1e-9 to 1e-9, so a sign that differs from the reference's is an error
+    of 2 pi in an observation.  Recorded: the reference's get_euler_xyz, and the twelve leading observation
+    columns of compute_ant_observations / compute_humanoid_observations (identity and tilted start rotation)."""
+    _install_gym_stubs()
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    ant = ref_shim.load("isaacgymenvs.tasks.ant")
+    hum = ref_shim.load("isaacgymenvs.tasks.humanoid")
+    rs = np.random.default_rng(seed)
+    deltas = np.array([0.0, 1e-9, -1e-9, 1e-8, -1e-8, 1e-7, -1e-7, 1e-6, -1e-6, 3e-10, -3e-10])
+    tiny = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-40, -1e-40, 1e-38, -1e-38, 1e-30, -1e-30, 1e-20, -1e-20, 1e-12, -1e-12,
+                     1e-9, -1e-9, 1e-7, -1e-7])
+    m = n // 5
+
+    def solve(kind, count):
+        """unit quaternions (fp64) with w x + y z = delta (kind 0) or w z + x y = delta (kind 1)"""
+        a, b = rs.normal(size=count), rs.normal(size=count)
+        w = rs.uniform(0.2, 1.0, size=count) * rs.choice([-1.0, 1.0], size=count)
+        d = rs.choice(deltas, size=count)
+        c = (d - a * b) / w
+        q = np.stack([c, a, b, w], -1) if kind == 0 else np.stack([a, b, c, w], -1)
+        return q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+    qa = solve(0, m)                       # roll numerator at noise level
+    qb = solve(1, m)                       # yaw numerator at noise level
+    # pure pitch plus tiny x and z: both numerators are 2 w delta, exactly representable tiny values
+    pitch = rs.uniform(-np.pi, np.pi, size=m)
+    qc = np.stack([rs.choice(tiny, size=m), np.sin(pitch / 2), rs.choice(tiny, size=m), np.cos(pitch / 2)], -1)
+    # roll / yaw near pi: the denominator is negative, the numerator tiny (atan2 -> +-pi)
+    ang = np.pi + rs.choice(deltas, size=m) * 10
+    half = rs.random(m) < 0.5
+    qd = np.where(half[:, None], np.stack([np.sin(ang / 2), 0 * ang, 0 * ang, np.cos(ang / 2)], -1),
+                  np.stack([0 * ang, 0 * ang, np.sin(ang / 2), np.cos(ang / 2)], -1))
+    qe = rs.normal(size=(n - 4 * m, 4))    # generic rotations, not normalised to the last bit
+    qe /= np.linalg.norm(qe, axis=-1, keepdims=True)
+    q = np.concatenate([qa, qb, qc, qd, qe]).astype(np.float32)
+    special = np.array([[0, 0, 0, 1], [0, 0, 0, -1], [0, 0, 1, 0], [1, 0, 0, 0], [0, 1, 0, 0], [-0.0, -0.0, 0, 1],
+                        [-0.0, 0, 0, -1], [0, -0.0, -0.0, 1], [0, 0, -0.0, -1], [-0.0, -0.0, -0.0, -1],
+                        [0.70710678, 0, 0, 0.70710678], [0, 0.70710678, 0, 0.70710678], [0, 0, 0.70710678, -0.70710678],
+                        [0.5, 0.5, 0.5, 0.5], [0.5, -0.5, 0.5, -0.5]], np.float32)
+    q[-len(special):] = special
+    q = torch.from_numpy(q)
+    root = torch.zeros(n, 13)
+    root[:, 0:3] = torch.from_numpy(rs.normal(size=(n, 3)).astype(np.float32)) * torch.tensor([3.0, 3.0, 0.2]) + torch.tensor([0.0, 0.0, 1.0])
+    root[:, 3:7] = q
+    root[:, 7:13] = torch.from_numpy(rs.normal(size=(n, 6)).astype(np.float32))
+    out = {"root": root}
+    r, p_, y = tj.get_euler_xyz(q)
+    out.update(euler_roll=r, euler_pitch=p_, euler_yaw=y)
+    targets1 = torch.tensor([1000.0, 0.0, 0.0])
+    tilt = torch.tensor([0.1, -0.2, 0.3, 0.9])
+    tilt = tilt / tilt.norm()
+    basis0, basis1 = torch.tensor([1.0, 0.0, 0.0]).repeat(n, 1), torch.tensor([0.0, 0.0, 1.0]).repeat(n, 1)
+    for tag, start_rot in (("", torch.tensor([0.0, 0.0, 0.0, 1.0])), ("_tilt", tilt)):
+        isr = tj.quat_conjugate(start_rot).repeat(n, 1)
+        for name, D, S in (("ant", 8, 24), ("hum", 21, 12)):
+            lo, hi = -torch.ones(D), torch.ones(D)
+            zeros = torch.zeros(n, D)
+            pot = torch.zeros(n)
+            if name == "ant":
+                obs = ant.compute_ant_observations(torch.zeros(n, 60), root.clone(), targets1.repeat(n, 1), pot, isr, zeros, zeros, lo, hi,
+                                                   0.2, torch.zeros(n, S), zeros, 0.0166, 0.1, basis0, basis1, 2)[0]
+            else:
+                obs = hum.compute_humanoid_observations(torch.zeros(n, 108), root.clone(), targets1.repeat(n, 1), pot, isr, zeros, zeros,
+                                                        zeros, lo, hi, 0.1, torch.zeros(n, S), zeros, 0.0166, 0.01, 0.25, basis0,
+                                                        basis1)[0]
+            out["%s_obs_head%s" % (name, tag)] = obs[:, :12].clone()
+        out["inv_start_rot" + tag] = isr[0].clone()
+    out = {k: v.numpy() for k, v in out.items()}
+    sr = 2.0 * (out["root"][:, 6] * out["root"][:, 3] + out["root"][:, 4] * out["root"][:, 5])
+    sy = 2.0 * (out["root"][:, 6] * out["root"][:, 5] + out["root"][:, 3] * out["root"][:, 4])
+    out["meta"] = _meta(task="angles_edge", n=n, seed=seed, dt=0.0166, targets=[1000.0, 0.0, 0.0])
+    np.savez_compressed(os.path.join(OUT, "angles_edge.npz"), **out)
+    print("angles_edge.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+          "|roll numerator| < 1e-6: %d (%d negative), |yaw numerator| < 1e-6: %d (%d negative); rolls at 2 pi: %d, yaws at 2 pi: %d" % (
+              (np.abs(sr) < 1e-6).sum(), ((np.abs(sr) < 1e-6) & (sr < 0)).sum(), (np.abs(sy) < 1e-6).sum(),
+              ((np.abs(sy) < 1e-6) & (sy < 0)).sum(), (out["euler_roll"] > 6.28).sum(), (out["euler_yaw"] > 6.28).sum()))
+
+
+GENERATORS = {"angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -43,16 +43,34 @@ def assert_close(x, ref, scale=1.0, rtol=RTOL, what=""):
                              (what, len(bad), ok.size, i, x[i], ref[i]))
 
 
-def assert_angle_close(x, ref, rtol=RTOL, what=""):
-    """angles: compare modulo 2*pi with scale pi."""
-    d = np.abs(np.asarray(x, np.float64) - np.asarray(ref, np.float64))
-    d = np.minimum(d, np.abs(d - 2 * np.pi))
-    ok = d <= rtol * np.maximum(np.abs(ref), np.pi)
+def assert_angle_close(x, ref, rtol=RTOL, what="", branch_cut=None):
+    """Angles at scale pi, STRICT: |x - ref| <= rtol * max(|ref|, pi) with no modulo-2-pi allowance.  The yaw /
+    roll / pitch of get_euler_xyz are `atan2(..) % 2 pi`: whether the 2 pi is added hangs on the sign of the
+    atan2 numerator, which is plain IEEE arithmetic and therefore the same everywhere; a result that sits 2 pi
+    away from the reference's is a wrong observation and fails here.
+
+    branch_cut="pi" is for values the reference itself sends through normalize_angle = atan2(sin a, cos a)
+    (Humanoid's yaw / roll / angle_to_target): within 1e-3 of +-pi the sign of sin(a) hangs on the last bit
+    of a and of the library's sin, so -pi and +pi are the same answer there, and only there.  Returns the
+    number of entries that used that allowance (0 without branch_cut)."""
+    x = np.asarray(x, np.float64)
+    ref = np.asarray(ref, np.float64)
+    d = np.abs(x - ref)
+    tol = rtol * np.maximum(np.abs(ref), np.pi)
+    ok = (d <= tol) | (np.isnan(x) & np.isnan(ref))
+    flipped = np.zeros_like(ok)
+    if branch_cut == "pi":
+        flipped = ~ok & (np.abs(ref) >= np.pi - 1e-3) & (np.abs(d - 2 * np.pi) <= tol)
+        ok = ok | flipped
+    elif branch_cut is not None:
+        raise ValueError(branch_cut)
     if not ok.all():
         bad = np.argwhere(~ok)
         i = tuple(bad[0])
-        raise AssertionError("%s: %d/%d angles outside tolerance; first at %s: got %r want %r" %
-                             (what, len(bad), ok.size, i, x[i], ref[i]))
+        wraps = int((~ok & (np.abs(d - 2 * np.pi) <= 1e-3)).sum())
+        raise AssertionError("%s: %d/%d angles outside tolerance (%d of them 2 pi away: wrap errors); first at %s: got %r want %r" %
+                             (what, len(bad), ok.size, wraps, i, x[i], ref[i]))
+    return int(flipped.sum())
 
 
 def bit_equal_fraction(x, ref):
@@ -91,6 +109,12 @@ def loco_params(meta, g, seed=0, rng_offset=0):
 # observation columns that go through atan2 / remainder (library-dependent
 # transcendental functions): yaw, roll, angle_to_target
 LOCO_ANGLE_COLS = (7, 8, 9)
+
+
+def loco_branch_cut(humanoid):
+    """Ant publishes the raw `% 2 pi` angles (strict comparison); Humanoid sends the three through
+    normalize_angle (humanoid.py:513-515), whose +-pi ends are one answer."""
+    return "pi" if humanoid else None
 
 
 ALLEGRO_VARIANTS = ["default", "full", "no_vel_asym", "pen_maxsucc", "relative", "ema", "force"]
@@ -689,3 +713,66 @@ class LocalShards:
         if err:
             raise err[0]
         return res
+
+
+# ---- angles_edge.npz: torso rotations whose roll / yaw atan2 numerators are zero, signed zero, subnormal
+# or rounding noise of both signs, recorded from the reference's get_euler_xyz / compute_*_observations ----
+def angles_edge_check(g, euler_fn, ant_step, humanoid_step, to_buf, to_np):
+    """euler_fn(q [n,4] numpy) -> (roll, pitch, yaw) numpy; *_step(params, bufs, n) on backend buffers.
+    Everything is compared strictly (no modulo 2 pi); returns {what: number of reference values at 2 pi}."""
+    from isaacgym_amd import synthetic
+    root = g["root"]
+    n = root.shape[0]
+    seen = {}
+    got = euler_fn(np.ascontiguousarray(root[:, 3:7]))
+    for name, x in zip(("euler_roll", "euler_pitch", "euler_yaw"), got):
+        assert_angle_close(np.asarray(x).reshape(-1), g[name], what="angles_edge " + name)
+        seen[name] = int((g[name] > 6.28).sum())
+    for tag in ("", "_tilt"):
+        for task, spec, step in (("ant", synthetic.ANT, ant_step), ("hum", synthetic.HUMANOID, humanoid_step)):
+            D, S, hum = spec["num_dof"], spec["num_sensor_floats"], spec["humanoid"]
+            p = synthetic.loco_params(spec)
+            p.set("inv_start_rot", g["inv_start_rot" + tag].tolist())
+            p.set("dof_limits_lower", [-1.0] * D)
+            p.set("dof_limits_upper", [1.0] * D)
+            z = lambda *shape, dt=np.float32: to_buf(np.zeros(shape, dt))  # noqa: E731
+            bufs = dict(root_states=to_buf(root), dof_state=z(n, D, 2), sensors=z(n, S), actions=z(n, D),
+                        initial_root_states=z(n, 13), initial_dof_pos=z(n, D), obs=z(n, spec["num_obs"]),
+                        potentials=z(n), prev_potentials=z(n), up_vec=z(n, 3), heading_vec=z(n, 3), rew=z(n),
+                        reset=z(n, dt=np.int64), progress=z(n, dt=np.int64), randomize=z(n, dt=np.int64))
+            if hum:
+                bufs["dof_force"] = z(n, D)
+            step(p, bufs, n)
+            obs, ref = to_np(bufs["obs"])[:, :12], g["%s_obs_head%s" % (task, tag)]
+            what = "angles_edge %s%s " % (task, tag)
+            nonangle = [c for c in range(12) if c not in LOCO_ANGLE_COLS]
+            assert bit_equal_fraction(obs[:, nonangle], ref[:, nonangle]) == 1.0, what + "non-angle columns"
+            flips = assert_angle_close(obs[:, list(LOCO_ANGLE_COLS)], ref[:, list(LOCO_ANGLE_COLS)], what=what + "yaw / roll / angle_to_target",
+                                       branch_cut=loco_branch_cut(hum))
+            seen[what + "at 2 pi"] = int((ref[:, 7:9] > 6.28).sum())
+            seen[what + "+-pi flips"] = flips
+    return seen
+
+
+def edge_quats(n, seed):
+    """[n,4] float32 rotations concentrated on the remainder wrap of get_euler_xyz: a quarter each with the roll
+    numerator 2(wx+yz) and the yaw numerator 2(wz+xy) solved to 0 / +-1e-9 .. +-1e-6 in fp64 (after rounding to
+    fp32 the sign is rounding noise), a quarter pure pitch with x and z from {+-0, subnormals, +-1e-30 .. +-1e-7},
+    a quarter generic."""
+    rs = np.random.default_rng(seed)
+    deltas = np.array([0.0, 1e-9, -1e-9, 1e-8, -1e-8, 1e-7, -1e-7, 1e-6, -1e-6, 3e-10, -3e-10])
+    tiny = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-40, -1e-40, 1e-38, -1e-38, 1e-30, -1e-30, 1e-20, -1e-20, 1e-12, -1e-12,
+                     1e-9, -1e-9, 1e-7, -1e-7])
+    m = n // 4
+    parts = []
+    for kind in (0, 1):
+        a, b = rs.normal(size=m), rs.normal(size=m)
+        w = rs.uniform(0.2, 1.0, size=m) * rs.choice([-1.0, 1.0], size=m)
+        c = (rs.choice(deltas, size=m) - a * b) / w
+        q = np.stack([c, a, b, w], -1) if kind == 0 else np.stack([a, b, c, w], -1)
+        parts.append(q / np.linalg.norm(q, axis=-1, keepdims=True))
+    pitch = rs.uniform(-np.pi, np.pi, size=m)
+    parts.append(np.stack([rs.choice(tiny, size=m), np.sin(pitch / 2), rs.choice(tiny, size=m), np.cos(pitch / 2)], -1))
+    q = rs.normal(size=(n - 3 * m, 4))
+    parts.append(q / np.linalg.norm(q, axis=-1, keepdims=True))
+    return np.ascontiguousarray(np.concatenate(parts).astype(np.float32)[rs.permutation(n)])

@@ -28,7 +28,7 @@ AFFINE = ["scale", "unscale", "tensor_clamp"]
 # The remaining functions of the module (tests/golden/math2.npz).  Each case:
 #   id, function name, arguments (golden keys; non-strings are passed as they are),
 #   output keys, class per output: "exact" (bit equality), "tol" (1e-5 of the given
-#   scale) or "angle" (1e-5, compared modulo 2 pi).
+#   scale) or "angle" (1e-5 at scale pi, strict: a value 2 pi away from the reference is an error).
 PI = float(np.pi)
 MULTI = [
     ("normalize3", "normalize", ("v",), ("normalize3",), ("exact",), 1.0),

@@ -60,7 +60,8 @@ def test_loco_fuzz(humanoid):
             assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, (k, what)
         obs = t["obs"].cpu().numpy()
         assert H.bit_equal_fraction(obs[:, nonangle], ref["obs"][:, nonangle]) == 1.0, what
-        H.assert_angle_close(obs[:, list(H.LOCO_ANGLE_COLS)], ref["obs"][:, list(H.LOCO_ANGLE_COLS)], what=what)
+        H.assert_angle_close(obs[:, list(H.LOCO_ANGLE_COLS)], ref["obs"][:, list(H.LOCO_ANGLE_COLS)], what=what,
+                             branch_cut=H.loco_branch_cut(humanoid))
         if "time_outs" in t:
             assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), what
             assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -p.clip_obs, p.clip_obs)), what

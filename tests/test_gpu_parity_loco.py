@@ -105,7 +105,7 @@ def _golden_loco(name, step, nobs, humanoid):
         obs = out["obs"].cpu().numpy()
         # tolerance bar of the task statement (1e-5 relative, natural scale) ...
         H.assert_close(obs[:, nonangle], g["obs"][t][:, nonangle], what="obs step %d" % t)
-        H.assert_angle_close(obs[:, ang], g["obs"][t][:, ang], what="obs angles step %d" % t)
+        H.assert_angle_close(obs[:, ang], g["obs"][t][:, ang], what="obs angles step %d" % t, branch_cut=H.loco_branch_cut(humanoid))
         H.assert_close(out["rew"].cpu().numpy(), g["rew"][t], what="rew step %d" % t)
         # ... and the stronger property the exact arithmetic model gives:
         for key, arr in (("out_dof_state", ds), ("potentials", pot), ("prev_potentials", out["prev_potentials"]),
@@ -157,7 +157,7 @@ def _vs_oracle(spec, step, ostep, n, with_rand, steps=2):
             assert np.array_equal(t[k].cpu().numpy(), ref[k]), "%s step %d" % (k, s)
         obs = t["obs"].cpu().numpy()
         assert H.bit_equal_fraction(obs[:, nonangle], ref["obs"][:, nonangle]) == 1.0, "obs step %d" % s
-        H.assert_angle_close(obs[:, ang], ref["obs"][:, ang], what="angles step %d" % s)
+        H.assert_angle_close(obs[:, ang], ref["obs"][:, ang], what="angles step %d" % s, branch_cut=H.loco_branch_cut(spec["humanoid"]))
         for k in ("dof_state", "potentials", "prev_potentials", "up_vec", "heading_vec", "rew"):
             assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, "%s step %d" % (k, s)
         assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), "time_outs step %d" % s

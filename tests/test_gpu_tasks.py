@@ -136,7 +136,8 @@ def test_locomotion_class_golden(name, cls, D, S):
             assert np.array_equal(host(getattr(task, k)), g[ref][t]), "%s step %d" % (k, t)
         obs = host(task.obs_buf)
         assert np.array_equal(bits(obs[:, nonangle]), bits(g["obs"][t][:, nonangle]))
-        H.assert_angle_close(obs[:, list(H.LOCO_ANGLE_COLS)], g["obs"][t][:, list(H.LOCO_ANGLE_COLS)], what="angles")
+        H.assert_angle_close(obs[:, list(H.LOCO_ANGLE_COLS)], g["obs"][t][:, list(H.LOCO_ANGLE_COLS)], what="angles",
+                             branch_cut=H.loco_branch_cut(hum))
         for k in ("potentials", "prev_potentials", "up_vec", "heading_vec"):
             assert np.array_equal(bits(host(getattr(task, k))), bits(g[k][t])), k
         assert np.array_equal(bits(host(rew)), bits(g["rew"][t]))

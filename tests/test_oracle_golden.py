@@ -74,7 +74,8 @@ def _run_loco(name, step_fn, nobs, humanoid):
         f = H.bit_equal_fraction(out["obs"][:, nonangle], g["obs"][t][:, nonangle])
         assert f == 1.0, "obs non-angle columns step %d: %f" % (t, f)
         H.assert_angle_close(out["obs"][:, list(H.LOCO_ANGLE_COLS)],
-                             g["obs"][t][:, list(H.LOCO_ANGLE_COLS)], what="obs angles step %d" % t)
+                             g["obs"][t][:, list(H.LOCO_ANGLE_COLS)], what="obs angles step %d" % t,
+                             branch_cut=H.loco_branch_cut(humanoid))
         if not humanoid:
             assert H.bit_equal_fraction(bufs["true_objective"], g["true_objective"][t]) == 1.0
     return stats
