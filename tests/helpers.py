@@ -357,21 +357,101 @@ def shadow_replay(g, pre_fn, post_fn, to_buf, to_np, zeros, force_fn=None):
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
 
-def assert_close_near_identity(x, ref, scale=1.0, rtol=RTOL, quantum=2e-2, max_frac=1e-4, what=""):
-    """assert_close for quantities derived from quat_to_angle_axis(slerp(...)) of a
-    nearly identity rotation.  fp32 slerp divides by sqrt(1 - c*c), which for close
-    frames is quantised to ~3e-5 relative, so its result is a unit quaternion only to
-    that precision; for an interpolated rotation within ~1e-2 rad of identity w can
-    land on exactly 1.0 (angle masked to zero, torch_jit_utils.py:423-444) or one ulp
-    below (angle*axis = 2*xyz) depending on the last bit of the math library's
-    acos / sin.  The reference has the same knife edge.  Such entries must be rare and
-    every difference outside rtol must stay below `quantum` rad."""
-    ok = close(x, ref, scale, rtol)
-    bad = ~ok
-    if bad.any():
-        d = np.abs(x[bad].astype(np.float64) - ref[bad])
-        assert bad.mean() <= max_frac, "%s: %d/%d outside tolerance" % (what, bad.sum(), bad.size)
-        assert (d < quantum).all(), "%s: max jump %g" % (what, d.max())
+# ---- HumanoidAMP observation columns (humanoid_amp_base.py:542-576, dof_to_obs :510-540) -----------------
+AMP_DOF_OFFSETS = [0, 3, 6, 9, 10, 13, 14, 17, 18, 21, 24, 25, 28]
+# (name, first column, one past the last, how the natural scale of the group is found)
+#   "exact": copies of inputs, bit for bit;  "unit": tan-norm / unit-range columns, scale 1;
+#   "row": rotated input vectors (root velocities, key-body offsets): scale = the largest vector norm of the row
+AMP_OBS_GROUPS = [("root_h", 0, 1, "exact"), ("root_rot tan-norm", 1, 7, "unit"), ("local root vel", 7, 10, "row"),
+                  ("local root ang vel", 10, 13, "row"), ("dof_obs", 13, 65, "unit"), ("dof_vel", 65, 93, "exact"),
+                  ("key body pos", 93, 105, "row")]
+
+
+def amp_joint_columns(kind):
+    """Per joint of DOF_OFFSETS the columns it owns: kind "dof_pos" -> in the 28-wide joint vector, "obs" -> in the
+    105-wide observation (three-DOF joints own six tan-norm columns of dof_obs, one-DOF joints one)."""
+    cols, o = [], 13
+    for a, b in zip(AMP_DOF_OFFSETS[:-1], AMP_DOF_OFFSETS[1:]):
+        if kind == "dof_pos":
+            cols.append(list(range(a, b)))
+        else:
+            w = 6 if b - a == 3 else 1
+            cols.append(list(range(o, o + w)))
+            o += w
+    return cols
+
+
+def amp_obs_errors(x, ref):
+    """Per column group of an [n,105] AMP observation: max of |x - ref| / max(|ref|, natural scale), as an array
+    over the entries (so a caller may exempt entries) plus the group table."""
+    x = np.asarray(x, np.float64).reshape(-1, 105)
+    ref = np.asarray(ref, np.float64).reshape(-1, 105)
+    err = np.zeros_like(ref)
+    for name, a, b, kind in AMP_OBS_GROUPS:
+        d = np.abs(x[:, a:b] - ref[:, a:b])
+        if kind == "exact":
+            err[:, a:b] = np.where(d == 0, 0.0, np.inf)
+            continue
+        scale = 1.0
+        if kind == "row":
+            v = ref[:, a:b].reshape(len(ref), -1, 3)
+            scale = np.sqrt((v * v).sum(-1)).max(-1, keepdims=True)
+        err[:, a:b] = d / np.maximum(np.abs(ref[:, a:b]), scale)
+    return err
+
+
+def assert_amp_obs_close(x, ref, what="", rtol=RTOL, exempt=None, quiet=False):
+    """The 1e-5 bar per column group, each group at its own natural scale; prints the largest error of every group
+    (in units of the tolerance' denominator).  `exempt`: boolean [n,105] of entries left out (knife-edge joints)."""
+    err = amp_obs_errors(x, ref)
+    if exempt is not None:
+        err = np.where(exempt.reshape(err.shape), 0.0, err)
+    worst = {name: (float(err[:, a:b].max()) if err.size else 0.0) for name, a, b, _ in AMP_OBS_GROUPS}
+    if not quiet:
+        print("%s max error per group (tolerance %.0e): %s" % (what, rtol, ", ".join("%s %.2e" % kv for kv in worst.items())))
+    bad = {k: v for k, v in worst.items() if not v <= rtol}
+    assert not bad, "%s: groups outside %.0e: %s" % (what, rtol, bad)
+    return worst
+
+
+def knife_edge_joints(got_dof_pos, want_dof_pos):
+    """quat_to_angle_axis masks a rotation to zero when sin(theta/2) = sqrt(1 - w*w) <= 1e-5, which in fp32 means
+    w == 1.0 exactly; one ulp below, the exp map is ~2 xyz (torch_jit_utils.py:423-444).  For an interpolated
+    rotation within ~1e-2 rad of identity, which side w lands on hangs on the last bit of the library's acos /
+    sin inside slerp; the reference has the same knife edge.  Returns (disagree [n,J] bool: the joint's rotation
+    is masked - all its components exactly 0 - on exactly one side, masked_want [n,J])."""
+    cols = amp_joint_columns("dof_pos")
+    g = np.stack([(got_dof_pos[:, c] == 0).all(-1) for c in cols], -1)
+    w = np.stack([(want_dof_pos[:, c] == 0).all(-1) for c in cols], -1)
+    return g ^ w, w
+
+
+def assert_close_near_identity(x, ref, scale=1.0, rtol=RTOL, quantum=2e-2, what="", disagree=None, kind="dof_pos",
+                               masked_want=None):
+    """assert_close for quantities derived from quat_to_angle_axis(slerp(...)): every entry outside rtol must belong
+    to a joint that `knife_edge_joints` found on the knife edge (masked on one side only), must stay below `quantum`
+    rad, and there must not be more such joints than the checker itself masks on the same inputs (the population
+    that sits on the edge).  The counts are printed.  `kind`: which array x is ("dof_pos" [n,28] or "obs" [n,105])."""
+    if kind == "obs":
+        bad = amp_obs_errors(x, ref) > rtol
+    else:
+        bad = ~close(x, ref, scale, rtol)
+    n_dis = 0 if disagree is None else int(disagree.sum())
+    n_masked = 0 if masked_want is None else int(masked_want.sum())
+    print("%s: %d/%d entries outside %.0e; joints masked on one side only: %d; joints the checker masks: %d" %
+          (what, int(bad.sum()), bad.size, rtol, n_dis, n_masked))
+    if not bad.any():
+        return
+    assert disagree is not None, "%s: %d entries outside tolerance" % (what, bad.sum())
+    allowed = np.zeros(bad.shape, bool)
+    for j, cols in enumerate(amp_joint_columns(kind)):
+        allowed[:, cols] |= disagree[:, j:j + 1]
+    stray = bad & ~allowed
+    assert not stray.any(), "%s: %d entries outside tolerance that are not on the identity knife edge; first %s" % (
+        what, stray.sum(), tuple(np.argwhere(stray)[0]))
+    d = np.abs(np.asarray(x, np.float64) - ref)[bad]
+    assert (d < quantum).all(), "%s: max jump %g" % (what, d.max())
+    assert n_dis <= max(8, n_masked), "%s: %d joints disagree, the checker masks only %d" % (what, n_dis, n_masked)
 
 
 def motion_tabs_from_golden(g):
@@ -466,9 +546,8 @@ def amp_replay(g, fns, to_buf, to_np, zeros):
             obs = to_np(b["obs"])
             mask = np.zeros(N, bool)
             mask[env_ids] = True
-            assert_close(obs[mask], g["reset_after_obs"][mask], scale=np.pi, rtol=2e-5, what="after reset: obs")
-            assert_close(to_np(b["amp_obs"])[mask], g["reset_after_amp_obs"][mask], scale=np.pi, rtol=2e-5,
-                         what="after reset: amp_obs")
+            assert_amp_obs_close(obs[mask], g["reset_after_obs"][mask], what="after reset: obs")
+            assert_amp_obs_close(to_np(b["amp_obs"])[mask], g["reset_after_amp_obs"][mask], what="after reset: amp_obs")
             put("obs", g["reset_after_obs"])
             put("amp_obs", g["reset_after_amp_obs"])
         put("root_states", g["in_root"][t])
@@ -480,9 +559,9 @@ def amp_replay(g, fns, to_buf, to_np, zeros):
         for k in ("reset", "terminate", "progress"):
             assert np.array_equal(to_np(b[k]), g[k][t]), what + k
         assert np.array_equal(to_np(b["rew"]), g["rew"][t]), what + "rew"
-        assert_close(to_np(b["obs"]), g["obs"][t], what=what + "obs")
+        assert_amp_obs_close(to_np(b["obs"]), g["obs"][t], what=what + "obs")
         amp = to_np(b["amp_obs"]).reshape(N, K * 105)
-        assert_close(amp[:, :105], g["amp_obs"][t][:, :105], what=what + "amp_obs current")
+        assert_amp_obs_close(amp[:, :105], g["amp_obs"][t][:, :105], what=what + "amp_obs current", quiet=True)
         if t != m["reset_before_step"] and t > 0:
             # history = previous step's current slot, bit for bit
             assert np.array_equal(amp[:, 105:210], prev_curr), what + "amp_obs history"

@@ -250,9 +250,8 @@ def test_amp_class_reset_draws_the_reference_samples(motion_lib):
     H.assert_close(host(task._dof_state).reshape(-1, 2), g["reset_after_dof_state"], scale=np.pi, what="dof")
     mask = np.zeros(N, bool)
     mask[g["reset_env_ids"]] = True
-    H.assert_close(host(task.obs_buf)[mask], g["reset_after_obs"][mask], scale=np.pi, rtol=2e-5, what="obs")
-    H.assert_close(host(task._amp_obs_buf)[mask], g["reset_after_amp_obs"][mask], scale=np.pi, rtol=2e-5,
-                   what="amp_obs")
+    H.assert_amp_obs_close(host(task.obs_buf)[mask], g["reset_after_obs"][mask], what="obs")
+    H.assert_amp_obs_close(host(task._amp_obs_buf)[mask], g["reset_after_amp_obs"][mask], what="amp_obs")
 
 
 def test_amp_fetch_demo_matches_unfused_path(motion_lib):
