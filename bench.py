@@ -11,8 +11,15 @@ shard into independent contiguous blocks (weak scaling: 2^20 envs per GPU), so
 the step path has no collective - RCCL is used for the barrier and for the
 MAX-over-ranks of the timed region only.
 
+With `--backend nccl` (the default) and more than one rank, an RCCL bring-up that
+fails on any rank ends every rank with a non-zero exit code; `--allow-gloo-fallback`
+lets the barrier and the MAX run over gloo instead, and the JSON names the backend
+of every collective that was used (`collectives`, `rccl_ranks`).
+
 Rank 0 prints ONE JSON line.  `value` is whole-job env-steps/s with all inputs
-resident in HBM.  `roofline` prices the dominant (only) kernel against the HBM
+resident in HBM.  After the headline measurement the other configurations of the
+path (Humanoid, AllegroHand post / pre, HumanoidAMP step, motion-library samples)
+are timed for ~50 launches each and reported under `configs`.  `roofline` prices the dominant (only) kernel against the HBM
 peak using 556 algorithmic bytes per env-step; `cpu_baseline` times the CPU
 checker (oracle/, a scalar C restatement of the reference's torch.jit path,
 OpenMP over envs) and the torch-op restatement of the reference's CPU pipeline
@@ -45,6 +52,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="with --backend nccl: if RCCL does not come up on every rank, run the barrier / MAX over gloo "
+                         "instead of failing (the JSON then says so)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other configurations (configs in the JSON)")
+    ap.add_argument("--config-steps", type=int, default=50, help="timed launches per extra configuration")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this device index instead of LOCAL_RANK")
     ap.add_argument("--force-group", action="store_true",
@@ -85,7 +97,7 @@ def cpu_baseline(spec, n, task, budget_s=10.0):
     host_cpus = os.cpu_count() or 1
     env_threads = os.environ.get("OMP_NUM_THREADS")
     threads = int(env_threads) if env_threads and env_threads.isdigit() else host_cpus
-    out = {"unit": "env-steps/s", "kind": "port", "host_cpus": host_cpus}
+    out = {"unit": "env-steps/s", "host_cpus": host_cpus}
 
     cores = oracle.set_num_threads(threads)
     p = synthetic.loco_params(spec, seed=1, rng_offset=0)
@@ -111,18 +123,26 @@ def cpu_baseline(spec, n, task, budget_s=10.0):
         out["torch_ref"] = {"value": n * steps / dt, "cores": tthreads,
                             "sample": "%d steps of %d envs (%s), %.1f s wall, unfused torch CPU ops (torch %s)"
                                       % (steps, n, task, dt, torch.__version__)}
-        head = out["torch_ref"]
+        head, kind = out["torch_ref"], "port"
+        out["headline_entry"] = "torch_ref"
     else:
-        head = out["port"]
-    out.update(value=head["value"], cores=head["cores"], sample=head["sample"])
+        head, kind = out["port"], "port"
+        out["headline_entry"] = "port"
+    # kind: neither entry is the reference's own code (it cannot travel to this box); both are this repository's
+    # restatements ("port").  `headline_entry` names the one value / cores / sample were taken from: the unfused
+    # torch-op pipeline is how the reference executes the step, the C + OpenMP restatement is the stronger CPU figure.
+    out.update(value=head["value"], cores=head["cores"], sample=head["sample"], kind=kind)
     return out
 
 
+TRAFFIC_FILE = "profiles/traffic_ant.json"
+
+
 def load_traffic():
-    """HBM bytes per launch from the committed PMC summary, if there is one."""
-    path = os.path.join(ROOT, "profiles", "traffic_ant.json")
+    """HBM bytes per launch from the committed PMC summary, if there is one: a constant read from a file of an
+    earlier rocprofv3 --pmc run of this same command, NOT a quantity of this run (the JSON says so)."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             d = json.load(f)
         return float(d["hbm_bytes_per_launch"])
     except Exception:
@@ -140,32 +160,190 @@ def launch_ranks(args):
     return rc
 
 
-def init_group(dist, torch, backend, dev):
-    """Join the job's process group.  The collectives of this benchmark are a barrier and one MAX of a scalar, so
-    when RCCL cannot come up on this node (it raises on every rank alike) the ranks meet again over gloo on the
-    next port instead of losing the measurement; the JSON line names the backend that was used."""
-    if backend == "nccl":
+class Group:
+    """The process groups of a run: `control` (gloo, host tensors: agreement between the ranks) and, when RCCL came
+    up on every rank, `device` (nccl = RCCL, device tensors).  `backend` is what the timed barrier / MAX use."""
+
+    def __init__(self, control, device, backend, rccl_ranks, note=None):
+        self.control, self.device, self.backend, self.rccl_ranks, self.note = control, device, backend, rccl_ranks, note
+
+    @property
+    def data(self):
+        return self.device if self.backend == "nccl" else self.control
+
+
+def init_group(dist, torch, backend, dev, allow_fallback, timeout_s=180.0):
+    """Join the job.  Every rank first joins a gloo group (the rendezvous torch.distributed.run or this script's own
+    launcher described in the environment); RCCL is then brought up as a second group on the same store and proved
+    with one all-reduce of ones on the device, whose result is the number of ranks RCCL reached.  Whether that
+    worked is agreed over gloo (MIN of the per-rank flags), so a failure on ONE rank is seen by all of them within
+    `timeout_s` and nobody is left waiting in a collective.  If RCCL failed anywhere: exit code 3 on every rank,
+    unless the caller allowed the fallback, in which case the timed barrier / MAX run over gloo."""
+    import datetime
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(timeout_s, 60.0) + 120.0))
+    control = dist.group.WORLD
+    world = dist.get_world_size()
+    if backend == "gloo":
+        return Group(control, None, "gloo", 0)
+    ok, err, device_group, reached = 1, "", None, 0
+    try:
+        kw = dict(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
         try:
-            dist.init_process_group("nccl", device_id=dev)
-            dist.barrier()
-            torch.cuda.synchronize()
-            return "nccl"
-        except Exception as e:  # noqa: BLE001 - any failure of the RCCL bring-up
-            print("bench: RCCL bring-up failed (%s: %s); using gloo for the barrier" % (type(e).__name__, e),
-                  file=sys.stderr, flush=True)
-            try:
-                dist.destroy_process_group()
-            except Exception:  # noqa: BLE001
-                pass
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-    dist.init_process_group("gloo")
-    return "gloo"
+            device_group = dist.new_group(device_id=dev, **kw)
+        except TypeError:  # a torch without new_group(device_id=)
+            device_group = dist.new_group(**kw)
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(ones, group=device_group)
+        torch.cuda.synchronize()
+        reached = int(ones.item())
+        if reached != world:
+            raise RuntimeError("RCCL all-reduce of ones over %d ranks returned %d" % (world, reached))
+    except Exception as e:  # noqa: BLE001 - any failure of the RCCL bring-up, on this rank
+        ok, err = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+        print("bench: RCCL bring-up failed on rank %d (%s)" % (dist.get_rank(), err), file=sys.stderr, flush=True)
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=control)
+    if int(flag.item()) == 1:
+        return Group(control, device_group, "nccl", reached)
+    if not allow_fallback:
+        print("bench: RCCL did not come up on every rank and --allow-gloo-fallback was not given: failing",
+              file=sys.stderr, flush=True)
+        dist.barrier(group=control)  # every rank has printed before the first one leaves
+        os._exit(3)  # not sys.exit: a rank stuck half-way in an RCCL communicator must not block interpreter shutdown
+    return Group(control, None, "gloo", 0, note="RCCL bring-up failed%s; --allow-gloo-fallback" % ((" (" + err + ")") if err else ""))
+
+
+def synthetic_motion_tables(torch, dev, num_motions=2, frames=300, fps=30.0, seed=0):
+    """Per-frame tables of `num_motions` synthetic clips in the layout igx_motion_tables takes (the reference's
+    motion files are not in its tree): smooth random rotations and positions, 15 bodies, 28 joint velocities."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    F = frames * num_motions
+
+    def smooth(*shape):
+        t = torch.linspace(0, 6.28, frames).repeat(num_motions).view(F, *([1] * len(shape)))
+        a, b = torch.randn(1, *shape, generator=g), torch.randn(1, *shape, generator=g)
+        return torch.sin(t * (1 + a.abs())) * 0.5 + b * 0.3
+
+    def unit(q):
+        return q / q.norm(dim=-1, keepdim=True)
+
+    ident = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    tabs = dict(
+        motion_length=torch.full((num_motions,), (frames - 1) / fps, dtype=torch.float64),
+        motion_dt=torch.full((num_motions,), 1.0 / fps, dtype=torch.float64),
+        motion_num_frames=torch.full((num_motions,), frames, dtype=torch.int64),
+        frame_offset=torch.arange(num_motions, dtype=torch.int64) * frames,
+        root_pos=smooth(3) + torch.tensor([0.0, 0.0, 0.9]), root_rot=unit(smooth(4) + ident),
+        local_rot=unit(smooth(15, 4) + ident), root_vel=smooth(3), root_ang_vel=smooth(3),
+        key_pos=smooth(4, 3), dof_vel=smooth(28))
+    return {k: v.contiguous().to(dev) for k, v in tabs.items()}
+
+
+def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world):
+    """The other configurations of the path, each timed with HIP events over `steps` launches on rotating input
+    sets (per rank; the slowest rank is reported when there are several).  For world > 1 the Humanoid shard also
+    runs the episode-statistics kernel every step and all-gathers the totals afterwards (configuration 3:
+    8 x 2^20 Humanoid environments with an RCCL all-gather of episode statistics)."""
+    from isaacgym_amd.episode_stats import EpisodeStats
+
+    def timed(fn, k=steps, warmup=5):
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(k):
+            fn(warmup + i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / k * 1e3
+        if group is not None and world > 1:
+            t = torch.tensor([us], dtype=torch.float64, device=dev if group.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group.data)
+            us = float(t.item())
+        return us
+
+    res = {}
+
+    def report(name, us, units, bytes_per_unit, what):
+        r = {"us": round(us, 2), "units": units, "units_per_s": units / us * 1e6, "what": what}
+        if bytes_per_unit:
+            gbps = units * bytes_per_unit / us / 1e3
+            r.update(bytes_per_unit=bytes_per_unit, GBps=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBPS, 4))
+        res[name] = r
+
+    # Humanoid (configuration 3's per-GPU shard)
+    p = synthetic.loco_params(synthetic.HUMANOID, seed=77 + rank, rng_offset=0)
+    sets = [synthetic.loco_state(synthetic.HUMANOID, n, 500 * rank + s, dev) for s in range(NUM_INPUT_SETS)]
+    for s in sets[1:]:
+        for k in ("potentials", "prev_potentials", "reset", "progress", "randomize", "obs", "up_vec", "heading_vec", "rew"):
+            s[k] = sets[0][k]
+    caches = [dict() for _ in sets]
+
+    def hum(i):
+        p.rng_offset = i
+        ops.humanoid_step(p, sets[i % NUM_INPUT_SETS], n, caches[i % NUM_INPUT_SETS])
+    report("humanoid_step", timed(hum), n, 940, "Humanoid fused post_physics_step, %d envs per GPU" % n)
+    if world > 1:
+        es = EpisodeStats(n, dev)
+
+        def hum_es(i):
+            hum(i)
+            es.step(sets[0]["rew"], sets[0]["reset"])
+        us = timed(hum_es)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tot = es.totals(group.data)
+        gather_us = (time.perf_counter() - t0) * 1e6
+        report("humanoid_step+episode_stats", us, n, 940 + 28,
+               "Humanoid step + episode-statistics kernel per step on every rank; totals all-gathered once over %s "
+               "(%d ranks, 32 B per rank, %.0f us on rank 0 incl. the read-back; %d episodes finished)"
+               % (group.backend, world, gather_us, tot[0]))
+    del sets, caches
+
+    # AllegroHand (configuration 4)
+    pa = synthetic.allegro_params("full_state", 1, 0)
+    sets = [synthetic.allegro_state(n, 300 * rank + s, dev) for s in range(3)]
+    caches = [dict() for _ in sets]
+    report("allegro_post", timed(lambda i: ops.allegro_post_physics(pa, sets[i % 3], n, caches[i % 3])), n, 748,
+           "AllegroHand post_physics_step (obs + compute_hand_reward + global sums), %d envs" % n)
+    caches = [dict() for _ in sets]
+    report("allegro_pre", timed(lambda i: ops.allegro_pre_physics(pa, sets[i % 3], n, caches[i % 3])), n, 272,
+           "AllegroHand pre_physics_step (flagged resets + action path), %d envs" % n)
+    del sets, caches
+
+    # HumanoidAMP step (configuration 5's environment side)
+    pm = synthetic.amp_params(2)
+    sets = [synthetic.amp_state(n, 200 * rank + s, dev, 2) for s in range(2)]
+    caches = [dict() for _ in sets]
+    report("humanoid_amp_step", timed(lambda i: ops.humanoid_amp_step(pm, sets[i % 2], n, caches[i % 2])), n, 2272,
+           "HumanoidAMP post_physics_step (obs + reset + AMP history shift, 2 history steps), %d envs; 2960 B/env "
+           "if the whole 780-B body rows are counted" % n)
+    del sets, caches
+
+    # motion library: fetch_amp_obs_demo's kernel (configuration 5: 1 024 trajectories per fetch)
+    tabs = synthetic_motion_tables(torch, dev)
+    tables = ops.motion_tables(tabs)
+    for m in (1024, 1 << 20):
+        gen = torch.Generator(device=dev).manual_seed(m + rank)
+        ids = torch.randint(0, 2, (m,), device=dev, generator=gen)
+        times = (torch.rand(m, device=dev, dtype=torch.float64, generator=gen) * tabs["motion_length"][ids]).contiguous()
+        out = torch.empty(m, 105, device=dev)
+        report("motion_amp_obs_%d" % m, timed(lambda i: ops.motion_amp_obs(tables, ids, times, False, out)), m, None,
+               "motion_lib frame blend + slerp + local-rotation-to-dof + build_amp_observations, %d samples per launch "
+               "(table gathers are cache resident: samples/s, no roofline)" % m)
+    return res
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))  # nothing above has touched the GPU
+    # standard output carries ONE JSON line and nothing else: libraries that write to file descriptor 1 themselves
+    # (gloo announces its connections there) are sent to standard error for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from isaacgym_amd import ops, synthetic
@@ -178,12 +356,13 @@ def main():
     dev_index = local_rank if args.all_ranks_on_device < 0 else args.all_ranks_on_device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    backend = args.backend
+    group = None
     grouped = world > 1 or args.force_group
     if grouped:
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
-        backend = init_group(dist, torch, args.backend, dev)
+        group = init_group(dist, torch, args.backend, dev, args.allow_gloo_fallback)
+    backend = group.backend if grouped else None
 
     spec = synthetic.ANT if args.task == "ant" else synthetic.HUMANOID
     step = ops.ant_step if args.task == "ant" else ops.humanoid_step
@@ -224,7 +403,7 @@ def main():
 
     def barrier():
         if grouped:
-            dist.barrier()
+            dist.barrier(group=group.data)  # RCCL: an all-reduce on the device; gloo: host
         torch.cuda.synchronize()
 
     run(0, args.warmup)
@@ -245,10 +424,17 @@ def main():
 
     if grouped:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group.data)
         elapsed = float(tt.item())
 
-    stats = es.totals() if es is not None else None  # one 32-byte-per-rank all-gather (RCCL when world > 1)
+    # one 32-byte-per-rank all-gather (over RCCL when it is up and world > 1)
+    stats = es.totals(group.data if grouped else None) if es is not None else None
+
+    configs = None
+    if not args.no_configs and args.task == "ant":
+        del sets, caches
+        torch.cuda.empty_cache()
+        configs = extra_configs(torch, dist, ops, synthetic, dev, n, args.config_steps, group, rank, world)
 
     if rank == 0:
         total_env_steps = float(n) * world * args.steps
@@ -264,22 +450,34 @@ def main():
                                    "layout, in-kernel Philox resets" % (args.task, n),
                        "envs_per_gpu": n, "global_envs": n * world, "input_sets": NUM_INPUT_SETS,
                        "parallelism": "env-shard x%d (no data-path collective)" % world,
-                       "collective_backend": backend if grouped else None},
+                       "collective_backend": backend},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": load_traffic() if args.task == "ant" and n == ENVS_PER_GPU else None,
+                         "traffic_source": ("%s (committed rocprofv3 --pmc run of this command, not measured by this run)"
+                                            % TRAFFIC_FILE) if args.task == "ant" and n == ENVS_PER_GPU else None,
                          "kernel_ms": kernel_ms, "bytes_per_env_step": bytes_per_env},
         }
+        if grouped:
+            out["rccl_ranks"] = group.rccl_ranks
+            out["collectives"] = {"rendezvous_and_agreement": "gloo", "barrier": backend, "max_of_elapsed": backend}
+            if es is not None or (configs and "humanoid_step+episode_stats" in configs):
+                out["collectives"]["episode_stats_all_gather"] = backend
+            if group.note:
+                out["collectives"]["note"] = group.note
+        if configs is not None:
+            out["configs"] = configs
         if stats is not None:
             out["episode_stats"] = {"episodes_finished": stats[0], "mean_reward": stats[1] / max(stats[0], 1),
                                     "mean_length": stats[2] / max(stats[0], 1), "steps": stats[3],
                                     "note": "extra kernel inside the timed region; totals all-gathered over the ranks"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, n, args.task)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
     if grouped:
-        dist.barrier()
+        dist.barrier(group=group.control)
         dist.destroy_process_group()
 
 

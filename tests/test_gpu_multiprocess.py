@@ -28,3 +28,50 @@ def test_rccl_paths_on_one_rank():
     rc, out = launch.spawn_ranks([sys.executable, "-u", tool], 1, timeout=110, env=env)
     assert rc == 0, out
     assert "window quantile over nccl ok, collectives per call: 2" in out and "queued shard records over nccl ok" in out
+
+
+# ---- bench.py's N > 1 path on a one-GPU box ------------------------------------------------------------
+BENCH = os.path.join(os.path.dirname(HERE), "bench.py")
+SMALL = ["--steps", "3", "--warmup", "1", "--envs-per-gpu", "65536", "--no-cpu-baseline", "--spawn-timeout", "100"]
+
+
+def _bench(*extra):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH] + SMALL + list(extra), env=env, capture_output=True, text=True, timeout=200)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return p.returncode, lines, p.stderr
+
+
+def test_bench_rccl_refusal_fails_the_run():
+    """Two ranks on ONE device: RCCL refuses the communicator ("Duplicate GPU detected").  A result line that was
+    quietly measured over another backend would be worthless as a scaling record, so the run must fail."""
+    rc, lines, err = _bench("--gpus", "2", "--all-ranks-on-device", "0", "--no-configs")
+    assert rc != 0, (lines, err[-2000:])
+    assert not lines, lines
+    assert "RCCL" in err
+
+
+def test_bench_fallback_flag_names_gloo():
+    rc, lines, err = _bench("--gpus", "2", "--all-ranks-on-device", "0", "--no-configs", "--allow-gloo-fallback")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert d["collectives"]["barrier"] == "gloo" and d["collectives"]["max_of_elapsed"] == "gloo"
+    assert "RCCL bring-up failed" in d["collectives"]["note"]
+
+
+def test_bench_world_of_one_through_rccl_with_configs():
+    """--force-group: the barrier and the MAX of the N > 1 path through RCCL as a world of one; the other
+    configurations of the path ride along in `configs`."""
+    rc, lines, err = _bench("--force-group", "--config-steps", "3")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["rccl_ranks"] == 1 and d["config"]["collective_backend"] == "nccl" and d["collectives"]["barrier"] == "nccl"
+    assert d["roofline"]["traffic"] is None  # the committed PMC figure belongs to the 2^20-env run only
+    for name in ("humanoid_step", "allegro_post", "allegro_pre", "humanoid_amp_step", "motion_amp_obs_1024",
+                 "motion_amp_obs_1048576"):
+        assert d["configs"][name]["us"] > 0, name
+    assert d["configs"]["humanoid_step"]["bytes_per_unit"] == 940 and "frac" in d["configs"]["humanoid_amp_step"]

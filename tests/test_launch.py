@@ -63,3 +63,23 @@ def test_bench_without_launcher_fails_cleanly_without_gpus():
     assert p.returncode != 0
     assert "rank" in p.stderr and "exited with code" in p.stderr
     assert not p.stdout.strip()
+
+
+def test_bench_group_rccl_failure_fails_every_rank():
+    """RCCL cannot come up here (no GPU): without --allow-gloo-fallback every rank leaves with code 3."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the GPU suite triggers the refusal with two ranks on one device")
+    rc, out = launch.spawn_ranks(CHILD + ["bench_group"], 2, timeout=150)
+    assert rc == 3
+    assert "{" not in out  # no result line
+
+
+def test_bench_group_fallback_names_gloo():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, out = launch.spawn_ranks(CHILD + ["bench_group_fallback"], 2, timeout=150)
+    assert rc == 0
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["backend"] == "gloo" and d["rccl_ranks"] == 0 and "RCCL bring-up failed" in d["note"] and d["sum"] == 3.0
