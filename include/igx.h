@@ -429,9 +429,15 @@ int igx_allegro_post_physics(const igx_allegro_params *p, const igx_allegro_buff
  * copy per GPU, held until the process ends.  n_envs above IGX_ALLEGRO_STATIC_MAX_ENVS is
  * IGX_E_SIZE.  The call allocates and frees nothing and gives the same results as
  * igx_allegro_post_physics.  Every call on one GPU uses that GPU's array: calls that overlap on
- * one GPU (two streams, two threads) race; calls on one stream, or ordered by events, do not. */
+ * one GPU (two streams, two threads) race; calls on one stream, or ordered by events, do not.
+ * The array's device address is looked up once per device: by igx_allegro_static_prepare() (a set-up
+ * call for the current device, no counterpart in the reference either; run it outside stream capture),
+ * or else by the first igx_allegro_post_physics_static call on that device - which therefore must not be
+ * made under capture (it is refused with IGX_E_PARAM if it is).  After that the entry point may be
+ * captured into a HIP graph and replayed. */
 #define IGX_ALLEGRO_STATIC_MAX_ENVS ((int64_t)1 << 21)
 #define IGX_ALLEGRO_STATIC_SCRATCH_BYTES (16 * ((1 << 21) / 16 + 1)) /* = IGX_ALLEGRO_WORKSPACE_BYTES(max) */
+int igx_allegro_static_prepare(void);
 int igx_allegro_post_physics_static(const igx_allegro_params *p, const igx_allegro_buffers *b,
                                     int64_t n_envs, igx_stream_t stream);
 

@@ -31,6 +31,7 @@ SYMBOLS = {
     "igx_allegro_pre_physics": _STEP_SIG,
     "igx_allegro_post_physics": _STEP_SIG,
     "igx_allegro_post_physics_static": _STEP_SIG,
+    "igx_allegro_static_prepare": (C.c_int, []),
     "igx_allegro_post_physics_shard": _STEP_SIG,
     "igx_allegro_finalize_shards": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "igx_allegro_finalize_shards_queued": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
@@ -273,6 +274,16 @@ def _launch(fn, dev, *args):
         return fn(*args, current_stream(dev))
 
 
+def _data_ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _storages(tensors):
+    """The storages behind `tensors`, to be kept with a cache entry: while they are alive the allocator cannot hand
+    their addresses to anything else, so a tensor re-pointed to NEW memory always shows a new data_ptr()."""
+    return [t.untyped_storage() for t in tensors if t is not None]
+
+
 def call_step(symbol, params, bufcls, tensors, n, cache=None):
     """One step entry point.  `cache` (a dict owned by the caller, one per task) keeps the validated buffer
     struct between calls: as long as the same tensor objects come back in `tensors` and n is unchanged, a
@@ -282,7 +293,9 @@ def call_step(symbol, params, bufcls, tensors, n, cache=None):
     if cache is not None:
         ids = tuple(map(id, tensors.values()))
         ent = cache.get(symbol)
-        if ent is not None and ent[0] == ids and ent[1] == n:
+        # same tensor objects, same n, and every one of them still points where it did when the struct was
+        # validated (`t.data = ...`, set_() and resize_() keep a tensor's identity but move its memory)
+        if ent is not None and ent[0] == ids and ent[1] == n and list(map(_data_ptr, ent[6])) == ent[7]:
             check(_launch(ent[2], ent[4], C.byref(params), ent[3], C.c_int64(n)))
             return
     check_sizes(bufcls, params, tensors, n, symbol)
@@ -291,7 +304,8 @@ def call_step(symbol, params, bufcls, tensors, n, cache=None):
         raise ValueError("no device buffers given")
     fn = getattr(lib(), symbol)
     if cache is not None:  # the entry keeps the tensors alive, so their ids cannot be reused while it exists
-        cache[symbol] = (ids, n, fn, C.byref(b), dev, b, list(tensors.values()))
+        held = list(tensors.values())
+        cache[symbol] = (ids, n, fn, C.byref(b), dev, b, held, list(map(_data_ptr, held)), _storages(held))
     check(_launch(fn, dev, C.byref(params), C.byref(b), C.c_int64(n)))
 
 

@@ -442,11 +442,32 @@ int scratch_address(void **out, const char *who)
 }
 }  // namespace
 
+// set-up call: resolves the array's address on the current device.  Meant to run once per device, outside
+// any stream capture (the lookup may load the code object); the entry point below then only reads the cached
+// address.  Calling it again is a table lookup.
+extern "C" int igx_allegro_static_prepare(void)
+{
+    void *ptr = nullptr;
+    return scratch_address(&ptr, "igx_allegro_static_prepare");
+}
+
 extern "C" int igx_allegro_post_physics_static(const igx_allegro_params *p, const igx_allegro_buffers *b, int64_t n,
                                                igx_stream_t stream)
 {
     const char *who = "igx_allegro_post_physics_static";
     if (!p || !b) return fail(IGX_E_NULL, "%s: params/buffers struct is NULL", who);
+    if (n > 0) {
+        // a first call per device that arrives while the stream is being captured must not start looking symbols
+        // up (not a stream operation, and unsafe inside a capture): it is refused with the remedy named
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices &&
+            !g_scratch_ptr[dev].load(std::memory_order_acquire)) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(IGX_E_PARAM, "%s: first call on device %d arrived under stream capture; call "
+                            "igx_allegro_static_prepare() on this device before capturing", who, dev);
+        }
+    }
     if (n > IGX_ALLEGRO_STATIC_MAX_ENVS)
         return fail(IGX_E_SIZE, "%s: n_envs %lld exceeds IGX_ALLEGRO_STATIC_MAX_ENVS (%lld); use igx_allegro_post_physics "
                     "with a caller-provided workspace", who, (long long)n, (long long)IGX_ALLEGRO_STATIC_MAX_ENVS);

@@ -46,6 +46,13 @@ def allegro_post_physics(params, tensors, n_envs, cache=None):
     _lib.call_step("igx_allegro_post_physics", params, _abi.AllegroBuffers, tensors, n_envs, cache)
 
 
+def allegro_static_prepare(device):
+    """Resolve the library-owned scratch of allegro_post_physics_static on `device` (once per device, outside
+    any graph capture); the step call can then be captured."""
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().igx_allegro_static_prepare())
+
+
 def allegro_post_physics_static(params, tensors, n_envs, cache=None):
     """igx_allegro_post_physics with the reduction records in the library's own file-scope device
     array: allocates nothing and ignores tensors['workspace'] (n_envs <= IGX_ALLEGRO_STATIC_MAX_ENVS)."""
@@ -316,7 +323,7 @@ def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0
     if cache is not None and noise is None:
         key = (id(actions), id(targets), id(actions_out), id(gain), id(offset), mode, power_scale, clip_actions, num_dof)
         ent = cache.get("igx_action_stage_step")
-        if ent is not None and ent[0] == key:
+        if ent is not None and ent[0] == key and list(map(_lib._data_ptr, ent[4])) == ent[5]:
             _lib.check(_lib._launch(_lib.lib().igx_action_stage_step, dev, ent[1], ent[2]))
             return
     modes = {"force": _abi.IGX_ACT_FORCE, "pd_target": _abi.IGX_ACT_PD_TARGET, "first_dof": _abi.IGX_ACT_FIRST_DOF}
@@ -344,7 +351,9 @@ def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0
     if noise is not None:
         s.noise = noise.struct(actions.numel(), fresh)
     if key is not None:
-        cache["igx_action_stage_step"] = (key, C.byref(s), C.c_int64(n), s, (actions, targets, actions_out, gain, offset))
+        held = (actions, targets, actions_out, gain, offset)
+        cache["igx_action_stage_step"] = (key, C.byref(s), C.c_int64(n), s, held, list(map(_lib._data_ptr, held)),
+                                          _lib._storages(held))
     _lib.check(_lib._launch(_lib.lib().igx_action_stage_step, dev, C.byref(s), C.c_int64(n)))
 
 
@@ -361,7 +370,7 @@ def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_ep
         key = (id(obs_buf), id(obs_out), id(progress), id(reset), id(time_outs), id(states_buf), id(states_out),
                clip_obs, max_episode_length)
         ent = cache.get("igx_vec_task_tail_step")
-        if ent is not None and ent[0] == key:
+        if ent is not None and ent[0] == key and list(map(_lib._data_ptr, ent[4])) == ent[5]:
             _lib.check(_lib._launch(_lib.lib().igx_vec_task_tail_step, dev, ent[1], ent[2]))
             return
     t = _abi.VecTaskTail()
@@ -387,8 +396,9 @@ def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_ep
     t.max_episode_length_m1 = float(max_episode_length - 1)
     t.clip_obs = float(clip_obs)
     if key is not None:
-        cache["igx_vec_task_tail_step"] = (key, C.byref(t), C.c_int64(n), t,
-                                           (obs_buf, obs_out, progress, reset, time_outs, states_buf, states_out))
+        held = (obs_buf, obs_out, progress, reset, time_outs, states_buf, states_out)
+        cache["igx_vec_task_tail_step"] = (key, C.byref(t), C.c_int64(n), t, held, list(map(_lib._data_ptr, held)),
+                                           _lib._storages(held))
     _lib.check(_lib._launch(_lib.lib().igx_vec_task_tail_step, dev, C.byref(t), C.c_int64(n)))
 
 
@@ -423,14 +433,15 @@ def _imitate_call(symbol, params, tensors, im, n_envs, cache=None):
     if cache is not None:
         ids = tuple(map(id, tensors.values()))
         ent = cache.get(symbol)
-        if ent is not None and ent[0] == ids and ent[1] == n_envs:
+        if ent is not None and ent[0] == ids and ent[1] == n_envs and list(map(_lib._data_ptr, ent[6])) == ent[7]:
             _lib.check(_lib._launch(ent[2], ent[4], C.byref(params), ent[3], C.byref(im), C.c_int64(n_envs)))
             return
     _lib.check_sizes(_abi.LocoBuffers, params, tensors, n_envs, symbol)
     b, dev = _lib.make_buffers(_abi.LocoBuffers, tensors)
     fn = getattr(_lib.lib(), symbol)
     if cache is not None:
-        cache[symbol] = (ids, n_envs, fn, C.byref(b), dev, b, list(tensors.values()))
+        held = list(tensors.values())
+        cache[symbol] = (ids, n_envs, fn, C.byref(b), dev, b, held, list(map(_lib._data_ptr, held)), _lib._storages(held))
     _lib.check(_lib._launch(fn, dev, C.byref(params), C.byref(b), C.byref(im), C.c_int64(n_envs)))
 
 

@@ -199,11 +199,13 @@ class AllegroHand(HandForcesMixin, VecTask):
 
     def _sharded_post(self, p, b):
         """One shard of a multi-GPU run.  The step itself exchanges nothing: its 16-byte record waits in a
-        device-side queue; every `statsSyncInterval` steps (env config, default 16; 0 = exchange on the step's
-        own stream every step, as round-trip-exact as the single-GPU value) the queues of all ranks are
-        gathered with one collective on a side stream and consecutive_successes is advanced over them in
-        step order (distributed.ShardRecordQueue)."""
-        interval = int(self.cfg["env"].get("statsSyncInterval", 16))
+        device-side queue.  Default (`statsSyncInterval` 0 in the env config): the records of all ranks are
+        gathered on the step's own stream every step and consecutive_successes is current after every step,
+        as in the reference.  With `statsSyncInterval: K` > 0 (opt-in) the queues of all ranks are gathered
+        once per K steps with one collective on a side stream and consecutive_successes is advanced over them
+        in step order (distributed.ShardRecordQueue): same bits, but what the task shows lags by up to two
+        intervals until sync_consecutive_successes() is called."""
+        interval = int(self.cfg["env"].get("statsSyncInterval", 0))
         if interval <= 0:
             ops.allegro_post_physics_shard(p, b, self.num_envs, self._call_cache)
             records = distributed.gather_records(self._workspace.view(torch.uint8)[:16], self._group)
@@ -218,7 +220,8 @@ class AllegroHand(HandForcesMixin, VecTask):
             q.flush(self._apply_shard_records)
 
     def sync_consecutive_successes(self):
-        """Bring consecutive_successes up to the last step (sharded runs keep it up to two sync intervals behind)."""
+        """Bring consecutive_successes up to the last step (sharded runs with statsSyncInterval > 0 keep it up to
+        two sync intervals behind)."""
         q = self.__dict__.get("_shard_queue")
         if q is not None:
             q.drain(self._apply_shard_records)
@@ -233,7 +236,8 @@ class AllegroHand(HandForcesMixin, VecTask):
         else:
             ops.allegro_post_physics(p, b, self.num_envs, self._call_cache)
         # .mean() of the one-element tensor (:393) is that element: a 0-dim view made once, no launch per step
-        self.extras["consecutive_successes"] = self._cons_scalar
+        # (with env.freshStepOutputs a copy, like everything else step() hands out: a learner may keep extras)
+        self.extras["consecutive_successes"] = self._cons_scalar.clone() if self.fresh_step_outputs else self._cons_scalar
         if self.print_success_stat:  # :395-404 (host prints: synchronises, as in the reference)
             self.total_resets = self.total_resets + self.reset_buf.sum()
             direct = self.total_successes + self.successes.sum()

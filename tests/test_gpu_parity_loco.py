@@ -324,3 +324,27 @@ def test_two_shards_draw_what_one_gpu_draws(spec, step):
     wrong = {k: (v[s:s + c].clone() if v is not None else None) for k, v in again.items()}
     step(synthetic.loco_params(spec, seed=77, rng_offset=5), wrong, c)  # env_offset forgotten: other draws
     assert not torch.equal(wrong["dof_state"], full["dof_state"][s:s + c])
+
+
+def test_cached_call_follows_a_repointed_tensor():
+    """The per-task argument cache is keyed on the tensor objects AND on where they point: a tensor whose storage
+    is swapped in place (`t.data = ...`) keeps its identity, and the cached struct must not launch on the old
+    address (stale data) or skip the size check (out-of-bounds access)."""
+    n = 1000
+    spec = synthetic.ANT
+    p = synthetic.loco_params(spec, seed=2, rng_offset=4)
+    t = synthetic.loco_state(spec, n, 21, DEV)
+    cache = {}
+    ops.ant_step(p, t, n, cache)
+    other = synthetic.loco_state(spec, n, 22, DEV)
+    start = {k: v.clone() for k, v in t.items()}
+    start["root_states"] = other["root_states"].clone()
+    t["root_states"].data = other["root_states"]      # same object, other memory
+    ops.ant_step(p, t, n, cache)
+    ops.ant_step(p, start, n)                          # uncached call from the same state
+    torch.cuda.synchronize()
+    for k in ("obs", "rew", "potentials", "reset", "progress"):
+        assert torch.equal(t[k], start[k]), k
+    t["root_states"].data = torch.zeros(n // 2, 13, device=DEV)   # new memory, too short for n environments
+    with pytest.raises(ValueError, match="root_states"):
+        ops.ant_step(p, t, n, cache)
