@@ -127,9 +127,11 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
                                                      float *__restrict__ obs, const int64_t *__restrict__ out_rows,
                                                      int64_t out_row_stride, int64_t out_col_offset)
 {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t s = gid >> 4;
-    const int item = (int)(gid & 15);
+    // a block owns 16 consecutive samples; thread t does work item t / 16 of sample t % 16, so that a wavefront
+    // holds four item kinds x 16 samples: three of the block's four waves run the joint path only and one runs
+    // root / key bodies / velocities, instead of every wave running all four paths one after the other
+    const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int item = (int)(threadIdx.x >> 4);
     if (s >= n) return;
     const int64_t id = ids[s];
     if (id < 0 || id >= t.num_motions) return;  // not a motion: this sample's output rows are left as they are
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
     float *orow = AMP_OBS ? obs + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset : nullptr;
 
     if (item < 12) {
-        const int j = item, body = DOF_BODY_IDS[j];
+        // items 0..7 are the eight 3-dof joints, 8..11 the four hinges (a nibble table: no memory access), so a
+        // wave's four items share one path
+        const int j = (int)((0xA753B9864210ULL >> (4 * item)) & 15), body = DOF_BODY_IDS[j];
         const f4 q = slerp(load_q(t.local_rot + (f.r0 * NB + body) * 4), load_q(t.local_rot + (f.r1 * NB + body) * 4),
                            f.blend);
         float d[3];
