@@ -332,6 +332,37 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
         report("motion_amp_obs_%d" % m, timed(lambda i: ops.motion_amp_obs(tables, ids, times, False, out)), m, None,
                "motion_lib frame blend + slerp + local-rotation-to-dof + build_amp_observations, %d samples per launch "
                "(table gathers are cache resident: samples/s, no roofline)" % m)
+
+    # a whole fetch_amp_obs_demo without the host (configuration 5: 512 trajectories x 2 history steps = 1 024 samples):
+    # the two draws on the device, then one launch that tiles over the history steps; and the same with every batch
+    # streamed to pinned host memory by the whole-row recorder on its side stream
+    from isaacgym_amd.recorder import TrajectoryRecorder
+    nb, K = 512, 2
+    cdf = torch.tensor([0.5, 1.0], dtype=torch.float64, device=dev)
+    d_ids = torch.empty(nb, dtype=torch.int64, device=dev)
+    d_times = torch.empty(nb, dtype=torch.float64, device=dev)
+    batch = torch.empty(nb, K * 105, device=dev)
+
+    def fetch(i):
+        ops.motion_sample(tables, cdf, d_ids, d_times, seed=5 + rank, rng_offset=i)
+        ops.motion_amp_obs_steps(tables, d_ids, d_times, K, 0.0332, False, batch)
+    report("amp_demo_fetch_device_sampling", timed(fetch, 4 * steps), nb * K, None,
+           "fetch_amp_obs_demo with device-side draws: igx_motion_sample + igx_motion_amp_obs_steps, %d trajectories x %d "
+           "history steps per fetch; no host transfer, no synchronisation" % (nb, K))
+    rec = TrajectoryRecorder(nb, K * 105, None, 4 * steps + 5, dev)
+
+    def fetch_and_stream(i):
+        fetch(i)
+        rec.capture(batch)
+    us = timed(fetch_and_stream, 4 * steps)
+    t0 = time.perf_counter()
+    host_batches = rec.finish()
+    drain_ms = (time.perf_counter() - t0) * 1e3
+    report("amp_demo_fetch_streamed_to_host", us, nb * K, None,
+           "the same with every [%d, %d] batch captured by the whole-row recorder (pinned host memory, side stream): "
+           "time per fetch on the producer stream; %d batches = %.1f MB on the host %.2f ms after the last fetch"
+           % (nb, K * 105, host_batches.shape[0], host_batches.numel() * 4 / 1e6, drain_ms))
+    rec.close()
     return res
 
 

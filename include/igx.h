@@ -686,6 +686,22 @@ int igx_motion_amp_obs(const igx_motion_tables *t, const int64_t *motion_ids, co
                        int64_t n, int32_t local_root_obs, float *out, const int64_t *out_rows,
                        int64_t out_row_stride, int64_t out_col_offset, igx_stream_t stream);
 
+/* HumanoidAMP.fetch_amp_obs_demo (tasks/humanoid_amp.py:146-171) after its two draws, in one launch: for drawn
+ * sample i (motion_ids[i], motion_times[i], i < n) and history step k < num_steps the observation of the motion at
+ * motion_times[i] + (-step_dt * k) (fp64, the operations of :156-159: np.tile of the ids, times0 + (-dt * arange))
+ * is written to out[(i * num_steps + k) * 105 ...]: out is the [n, num_steps * 105] batch the learner receives.
+ * Equals igx_motion_amp_obs on the tiled lists bit for bit; the host sends n ids and times instead of n * num_steps. */
+int igx_motion_amp_obs_steps(const igx_motion_tables *t, const int64_t *motion_ids, const double *motion_times, int64_t n,
+                             int32_t num_steps, double step_dt, int32_t local_root_obs, float *out, igx_stream_t stream);
+
+/* The two draws of fetch_amp_obs_demo on the device (MotionLib.sample_motions / sample_time,
+ * tasks/amp/utils_amp/motion_lib.py:61-78): motion_ids[i] = first j with u0 < cdf[j], motion_times[i] = u1 * length
+ * (0 with random_time == 0), u0 / u1 from the Philox stream keyed by (seed, rng_offset, i + env_offset) as in
+ * igx_motion_sample_flagged with every flag set; ref_init_prob is ignored.  The distributions are the
+ * reference's, the stream is not numpy's. */
+int igx_motion_sample(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int64_t *motion_ids,
+                      double *motion_times, igx_stream_t stream);
+
 typedef struct igx_amp_params {
     int32_t num_amp_obs_steps;        /* env.numAMPObsSteps >= 2 */
     int32_t local_root_obs;           /* env.localRootObs */
@@ -835,11 +851,15 @@ int igx_clamp(const float *x, float lo, float hi, float *out, int64_t count, igx
  * 128 MiB (at most 64 steps) per copy; the producer waits only when the ring of slots is full, i.e. when
  * it produces faster than the host link drains.
  * Host layout: [max_steps][num_cols][n_rows] fp32 (step-major), pinned.
+ * With cols == NULL (and num_cols == 0) a capture takes the whole buffer as it is - host layout
+ * [max_steps][n_rows][row_width]: the batches of HumanoidAMP.fetch_amp_obs_demo (tasks/humanoid_amp.py:146-171,
+ * [num_samples, numAMPObsSteps * 105]) streamed to the host as they are sampled.
  * ---------------------------------------------------------------------- */
 typedef struct igx_recorder igx_recorder;
 
 /* Allocates the staging ring (ring_slots slots of 1..64 steps of num_cols x n_rows floats on the
- * current device) and the pinned host buffer.  cols: column indices into a row of row_width. */
+ * current device) and the pinned host buffer.  cols: column indices into a row of row_width (at most 1024),
+ * or NULL with num_cols == 0 for whole rows. */
 int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t row_width, const int32_t *cols,
                         int32_t num_cols, int32_t ring_slots, int64_t max_steps);
 /* Capture src [n_rows,row_width] (device) as the next step; asynchronous.

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
                                                      const double *__restrict__ times, int64_t n,
                                                      const igx_motion_state_out o, int local_root_obs,
                                                      float *__restrict__ obs, const int64_t *__restrict__ out_rows,
-                                                     int64_t out_row_stride, int64_t out_col_offset)
+                                                     int64_t out_row_stride, int64_t out_col_offset, int steps,
+                                                     double step_dt)
 {
     // a block owns 16 consecutive samples; thread t does work item t / 16 of sample t % 16, so that a wavefront
     // holds four item kinds x 16 samples: three of the block's four waves run the joint path only and one runs
@@ -133,9 +134,14 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
     const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
     const int item = (int)(threadIdx.x >> 4);
     if (s >= n) return;
-    const int64_t id = ids[s];
+    // steps > 1: row s is history step k of drawn sample s / steps, at time t0 + (-dt * k) - the tiling of
+    // fetch_amp_obs_demo (tasks/humanoid_amp.py:156-159) done here instead of on the host (fp64, same operations)
+    const int64_t src = steps > 1 ? s / steps : s;
+    const int64_t id = ids[src];
     if (id < 0 || id >= t.num_motions) return;  // not a motion: this sample's output rows are left as they are
-    const FrameBlend f = calc_frame_blend(t, id, times[s]);
+    double time = times[src];
+    if (steps > 1) time = time + (-step_dt * (double)(s - src * steps));
+    const FrameBlend f = calc_frame_blend(t, id, time);
     float *orow = AMP_OBS ? obs + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset : nullptr;
 
     if (item < 12) {
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256) void motion_sample_flagged_kernel(const igx_mo
     if (e >= n) return;
     int64_t id = -1, env = -1, denv = -1;
     double time = 0.0;
-    if (reset[e] != 0) {
+    if (!reset || reset[e] != 0) {
         float u[4];
         philox_uniform4(s.seed, rng_offset_of(s.rng_offset, s.rng_offset_dev), e + s.env_offset, 0, u);
         if (u[2] < s.ref_init_prob) {
@@ -600,7 +606,7 @@ __global__ __launch_bounds__(256) void motion_sample_flagged_kernel(const igx_mo
             denv = e;
         }
     }
-    env_ids[e] = env;
+    if (env_ids) env_ids[e] = env;
     motion_ids[e] = id;
     motion_times[e] = time;
     if (default_env_ids) default_env_ids[e] = denv;
@@ -651,7 +657,7 @@ extern "C" int igx_motion_state(const igx_motion_tables *t, const int64_t *ids, 
     if (!ids || !times || !out) return fail(IGX_E_NULL, "igx_motion_state: NULL argument");
     const int64_t blocks = (n * 16 + 255) / 256;
     hipLaunchKernelGGL((motion_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
-                       ids, times, n, *out, 0, nullptr, nullptr, (int64_t)0, (int64_t)0);
+                       ids, times, n, *out, 0, nullptr, nullptr, (int64_t)0, (int64_t)0, 1, 0.0);
     return launch_status("igx_motion_state");
 }
 
@@ -668,8 +674,43 @@ extern "C" int igx_motion_amp_obs(const igx_motion_tables *t, const int64_t *ids
     igx_motion_state_out none = {};
     const int64_t blocks = (n * 16 + 255) / 256;
     hipLaunchKernelGGL((motion_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
-                       ids, times, n, none, (int)local_root_obs, out, out_rows, out_row_stride, out_col_offset);
+                       ids, times, n, none, (int)local_root_obs, out, out_rows, out_row_stride, out_col_offset, 1, 0.0);
     return launch_status("igx_motion_amp_obs");
+}
+
+extern "C" int igx_motion_amp_obs_steps(const igx_motion_tables *t, const int64_t *ids, const double *times, int64_t n,
+                                        int32_t num_steps, double step_dt, int32_t local_root_obs, float *out,
+                                        igx_stream_t stream)
+{
+    int rc = check_tables(t, "igx_motion_amp_obs_steps");
+    if (rc != IGX_OK) return rc;
+    if (num_steps < 1 || num_steps > 64) return fail(IGX_E_SIZE, "igx_motion_amp_obs_steps: num_steps %d", num_steps);
+    if (n < 0 || n > ((int64_t)1 << 32) / num_steps) return fail(IGX_E_SIZE, "igx_motion_amp_obs_steps: n out of range");
+    if (n == 0) return IGX_OK;
+    if (!ids || !times || !out) return fail(IGX_E_NULL, "igx_motion_amp_obs_steps: NULL argument");
+    igx_motion_state_out none = {};
+    const int64_t rows = n * num_steps;
+    const int64_t blocks = (rows * 16 + 255) / 256;
+    hipLaunchKernelGGL((motion_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
+                       ids, times, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0, (int)num_steps,
+                       step_dt);
+    return launch_status("igx_motion_amp_obs_steps");
+}
+
+extern "C" int igx_motion_sample(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int64_t *motion_ids,
+                                 double *motion_times, igx_stream_t stream)
+{
+    int rc = check_tables(t, "igx_motion_sample");
+    if (rc != IGX_OK) return rc;
+    if (!s) return fail(IGX_E_NULL, "igx_motion_sample: sampler struct is NULL");
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "igx_motion_sample: n out of range");
+    if (n == 0) return IGX_OK;
+    if (!s->cdf || !motion_ids || !motion_times) return fail(IGX_E_NULL, "igx_motion_sample: NULL argument");
+    igx_motion_sampler all = *s;
+    all.ref_init_prob = 2.0f;  // every draw is a motion (u2 < 2 always)
+    hipLaunchKernelGGL(motion_sample_flagged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *t, all, nullptr, n, nullptr, motion_ids, motion_times, nullptr);
+    return launch_status("igx_motion_sample");
 }
 
 extern "C" int igx_amp_observations(const float *root_states, const float *dof_pos, const float *dof_vel,

@@ -30,8 +30,8 @@ struct igx_recorder {
     int32_t row_width = 0, num_cols = 0, ring_slots = 0;
     int device = -1;
     int32_t *d_cols = nullptr;
-    float *d_ring = nullptr;   // [ring_slots][batch][num_cols][n_rows]
-    float *h_data = nullptr;   // [max_steps][num_cols][n_rows], pinned
+    float *d_ring = nullptr;   // [ring_slots][batch][num_cols][n_rows]  (whole rows: [..][n_rows][row_width])
+    float *h_data = nullptr;   // [max_steps][num_cols][n_rows], pinned   (whole rows: [max_steps][n_rows][row_width])
     float *h_data_dev = nullptr;  // the same memory as the device addresses it
     int drain_blocks = 0;      // > 0: copy with recorder_drain_kernel on that many workgroups; 0: hipMemcpyAsync
     hipStream_t copy_stream = nullptr;
@@ -51,6 +51,20 @@ __global__ __launch_bounds__(256) void recorder_gather_kernel(const float *__res
     if (row >= n_rows) return;
     const float *r = src + row * row_width;
     for (int c = 0; c < num_cols; ++c) st_stream(out + (int64_t)c * n_rows + row, r[cols[c]]);
+}
+
+// whole-row capture (cols == NULL at creation): the [n_rows, row_width] buffer as it is, 16 bytes per lane
+__global__ __launch_bounds__(256) void recorder_rows_kernel(const float *__restrict__ src, float *__restrict__ out,
+                                                            int64_t floats, int vec)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = floats / 4;
+        if (i < n4) st_stream(reinterpret_cast<v4f *>(out) + i, ld_stream(reinterpret_cast<const v4f *>(src) + i));
+        if (i < floats - 4 * n4) out[4 * n4 + i] = src[4 * n4 + i];
+    } else {
+        for (int64_t k = 4 * i; k < floats && k < 4 * i + 4; ++k) out[k] = src[k];
+    }
 }
 
 // staging slot -> pinned host memory by a kernel of a few workgroups (the host buffer is mapped into the
@@ -88,12 +102,15 @@ using namespace igx;
 extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t row_width, const int32_t *cols,
                                    int32_t num_cols, int32_t ring_slots, int64_t max_steps)
 {
-    if (!out || !cols) return fail(IGX_E_NULL, "igx_recorder_create: NULL argument");
+    if (!out) return fail(IGX_E_NULL, "igx_recorder_create: NULL argument");
     *out = nullptr;
-    if (n_rows <= 0 || row_width <= 0 || num_cols <= 0 || num_cols > 1024 || ring_slots < 1 || ring_slots > 64 ||
-        max_steps <= 0)
+    const bool whole_rows = cols == nullptr;  // every column, rows kept as they are
+    if (whole_rows && num_cols != 0) return fail(IGX_E_NULL, "igx_recorder_create: cols is NULL but num_cols is %d", num_cols);
+    if (whole_rows) num_cols = row_width;
+    if (n_rows <= 0 || row_width <= 0 || num_cols <= 0 || (!whole_rows && num_cols > 1024) || ring_slots < 1 ||
+        ring_slots > 64 || max_steps <= 0)
         return fail(IGX_E_SIZE, "igx_recorder_create: bad sizes");
-    for (int c = 0; c < num_cols; ++c)
+    for (int c = 0; !whole_rows && c < num_cols; ++c)
         if (cols[c] < 0 || cols[c] >= row_width) return fail(IGX_E_PARAM, "igx_recorder_create: column %d out of range", cols[c]);
     const int64_t slab = (int64_t)num_cols * n_rows;
     if (slab > ((int64_t)1 << 40) / max_steps) return fail(IGX_E_SIZE, "igx_recorder_create: host buffer too large");
@@ -109,8 +126,10 @@ extern "C" int igx_recorder_create(igx_recorder **out, int64_t n_rows, int32_t r
     r->batch = r->batch < 1 ? 1 : r->batch > 64 ? 64 : r->batch;
     if (r->batch > max_steps) r->batch = max_steps;
     REC_HIP(hipGetDevice(&r->device), "hipGetDevice");
-    REC_HIP(hipMalloc(&r->d_cols, sizeof(int32_t) * num_cols), "hipMalloc(cols)");
-    REC_HIP(hipMemcpy(r->d_cols, cols, sizeof(int32_t) * num_cols, hipMemcpyHostToDevice), "hipMemcpy(cols)");
+    if (!whole_rows) {
+        REC_HIP(hipMalloc(&r->d_cols, sizeof(int32_t) * num_cols), "hipMalloc(cols)");
+        REC_HIP(hipMemcpy(r->d_cols, cols, sizeof(int32_t) * num_cols, hipMemcpyHostToDevice), "hipMemcpy(cols)");
+    }
     REC_HIP(hipMalloc(&r->d_ring, sizeof(float) * slab * r->batch * ring_slots), "hipMalloc(ring)");
     REC_HIP(hipHostMalloc(&r->h_data, sizeof(float) * slab * max_steps, hipHostMallocMapped), "hipHostMalloc");
     r->drain_blocks = tuning_int("IGX_RECORDER_DRAIN_BLOCKS", 16);
@@ -173,8 +192,14 @@ extern "C" int igx_recorder_capture(igx_recorder *r, const float *src, igx_strea
     const int64_t slab = (int64_t)r->num_cols * r->n_rows;
     float *stage = r->d_ring + slab * (slot * r->batch + pos);
     if (pos == 0 && batch_index >= r->ring_slots) REC_HIP(hipStreamWaitEvent(ps, r->slot_free[slot], 0), "wait(slot_free)");
-    hipLaunchKernelGGL(recorder_gather_kernel, dim3((unsigned)((r->n_rows + 255) / 256)), dim3(256), 0, ps, src,
-                       (int)r->row_width, r->d_cols, (int)r->num_cols, r->n_rows, stage);
+    if (r->d_cols) {
+        hipLaunchKernelGGL(recorder_gather_kernel, dim3((unsigned)((r->n_rows + 255) / 256)), dim3(256), 0, ps, src,
+                           (int)r->row_width, r->d_cols, (int)r->num_cols, r->n_rows, stage);
+    } else {
+        const int vec = aligned16(src) && aligned16(stage);
+        hipLaunchKernelGGL(recorder_rows_kernel, dim3((unsigned)((slab / 4 + 256) / 256)), dim3(256), 0, ps, src, stage, slab,
+                           vec);
+    }
     int rc = launch_status("igx_recorder_capture");
     if (rc != IGX_OK) return rc;
     r->steps += 1;

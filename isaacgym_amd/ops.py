@@ -229,6 +229,42 @@ def motion_amp_obs(tables, motion_ids, motion_times, local_root_obs, out, out_ro
     _lib.check(rc)
 
 
+def motion_amp_obs_steps(tables, motion_ids, motion_times, num_steps, step_dt, local_root_obs, out):
+    """fetch_amp_obs_demo after its draws, in one launch: out[i, k*105:(k+1)*105] = observation of motion
+    motion_ids[i] at motion_times[i] + (-step_dt * k), k < num_steps (out: [n, num_steps * 105], contiguous)."""
+    dev = motion_ids.device
+    n = motion_ids.shape[0]
+    if motion_times.shape[0] != n:
+        raise ValueError("igx_motion_amp_obs_steps: motion_ids and motion_times differ in length")
+    if not out.is_contiguous() or out.numel() < n * num_steps * _abi.IGX_AMP_OBS:
+        raise ValueError("igx_motion_amp_obs_steps: out must be contiguous and hold %d x %d x %d floats" %
+                         (n, num_steps, _abi.IGX_AMP_OBS))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_motion_amp_obs_steps(C.byref(tables), _lib.tensor_ptr(motion_ids, torch.int64),
+                                                 _lib.tensor_ptr(motion_times, torch.float64), C.c_int64(n),
+                                                 C.c_int32(int(num_steps)), C.c_double(float(step_dt)),
+                                                 C.c_int32(int(bool(local_root_obs))), _lib.tensor_ptr(out, torch.float32),
+                                                 _lib.current_stream(dev))
+    _lib.check(rc)
+
+
+def motion_sample(tables, cdf, motion_ids, motion_times, random_time=True, seed=0, rng_offset=0, rng_offset_dev=None,
+                  env_offset=0):
+    """MotionLib.sample_motions + sample_time for every entry of motion_ids / motion_times [n], on the device
+    (the library's Philox stream; the distributions are the reference's)."""
+    dev = motion_ids.device
+    n = motion_ids.shape[0]
+    if motion_times.shape[0] != n:
+        raise ValueError("igx_motion_sample: motion_ids and motion_times differ in length")
+    s = _abi.MotionSampler(cdf=_lib.tensor_ptr(cdf, torch.float64), random_time=int(bool(random_time)), seed=int(seed),
+                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev, ref_init_prob=1.0,
+                           env_offset=int(env_offset))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_motion_sample(C.byref(tables), C.byref(s), C.c_int64(n), _lib.tensor_ptr(motion_ids, torch.int64),
+                                          _lib.tensor_ptr(motion_times, torch.float64), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 def amp_observations(root_states, dof_pos, dof_vel, key_body_pos, local_root_obs, obs):
     dev = obs.device
     f = torch.float32

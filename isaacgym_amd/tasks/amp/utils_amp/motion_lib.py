@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import yaml
 
-from .... import _abi, _lib
+from .... import _abi, _lib, ops
 
 # tasks/amp/humanoid_amp_base.py:43-44
 DOF_BODY_IDS = [1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 13, 14]
@@ -298,6 +298,24 @@ class MotionLib:
                                                _lib.current_stream(dev))
         _lib.check(rc)
         self._last_rows = rows_t  # released when the next call replaces it: by then this launch has been enqueued
+        return out
+
+    def get_amp_obs_steps(self, motion_ids, motion_times, num_steps, step_dt, local_root_obs, out):
+        """The batch of fetch_amp_obs_demo (humanoid_amp.py:146-171) for drawn (ids, times0): out[i, k] = observation
+        of motion ids[i] at times0[i] + (-step_dt * k).  One launch; the host sends n ids and times, the tiling over
+        the history steps happens in the kernel (same fp64 operations)."""
+        ids, times = self._to_device(motion_ids, motion_times)
+        ops.motion_amp_obs_steps(self._tables, ids, times, num_steps, step_dt, local_root_obs, out)
+        return out
+
+    def sample_on_device(self, n, seed, rng_offset, random_time=True, out=None):
+        """sample_motions + sample_time for n samples without the host: (ids int64 [n], times float64 [n]) on the
+        device, drawn from the library's Philox stream keyed by (seed, rng_offset, sample index)."""
+        dev = self._device
+        if out is None:
+            out = (torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.float64, device=dev))
+        ops.motion_sample(self._tables, self.sampling_cdf(), out[0], out[1], random_time=random_time, seed=seed,
+                          rng_offset=rng_offset)
         return out
 
     # ---- loading ------------------------------------------------------------

@@ -214,11 +214,38 @@ class HumanoidAMP(HumanoidAMPBase):
         else:
             assert self._amp_obs_demo_buf.shape[0] == num_samples
         motion_times0 = self._motion_lib.sample_time(motion_ids)
-        motion_ids = np.tile(np.expand_dims(motion_ids, axis=-1), [1, self._num_amp_obs_steps])
-        motion_times = np.expand_dims(motion_times0, axis=-1) + (-dt * np.arange(0, self._num_amp_obs_steps))
-        self._motion_lib.get_amp_obs(motion_ids.flatten(), motion_times.flatten(), self._local_root_obs,
-                                     out=self._amp_obs_demo_buf, out_row_stride=NUM_AMP_OBS_PER_STEP)
+        # :156-159 tile the ids over the history steps and step the times back by dt; the kernel does that itself
+        # (same fp64 operations), so the host sends num_samples ids / times instead of num_samples * steps
+        self._motion_lib.get_amp_obs_steps(motion_ids, motion_times0, self._num_amp_obs_steps, dt, self._local_root_obs,
+                                           self._amp_obs_demo_buf)
         return self._amp_obs_demo_buf.view(-1, self.get_num_amp_obs())
+
+    def fetch_amp_obs_demo_device(self, num_samples, seed=0):
+        """fetch_amp_obs_demo with its two draws made on the device (MotionLib.sample_on_device): nothing crosses
+        the host link and nothing synchronises, so a fetch is two launches.  The distributions are the reference's
+        (motion by weight, uniform phase); the random stream is the library's Philox, keyed by (seed, fetch count,
+        sample index), not numpy's - use fetch_amp_obs_demo to reproduce a numpy-seeded sequence."""
+        if self._amp_obs_demo_buf is None:
+            self._build_amp_obs_demo_buf(num_samples)
+        else:
+            assert self._amp_obs_demo_buf.shape[0] == num_samples
+        w = self.__dict__.get("_demo_draws")
+        if w is None or w[0].shape[0] != num_samples:
+            w = self._demo_draws = (torch.empty(num_samples, dtype=torch.int64, device=self.device),
+                                    torch.empty(num_samples, dtype=torch.float64, device=self.device))
+        self._demo_fetches = self.__dict__.get("_demo_fetches", 0) + 1
+        self._motion_lib.sample_on_device(num_samples, seed, self._demo_fetches, out=w)
+        ops.motion_amp_obs_steps(self._motion_lib._tables, w[0], w[1], self._num_amp_obs_steps, self.dt,
+                                 self._local_root_obs, self._amp_obs_demo_buf)
+        return self._amp_obs_demo_buf.view(-1, self.get_num_amp_obs())
+
+    def stream_amp_obs_demo(self, recorder, num_samples, device_sampling=True, seed=0):
+        """One fetch, handed to a whole-row TrajectoryRecorder (recorder.TrajectoryRecorder(num_samples,
+        get_num_amp_obs(), None, max_fetches, device)): the batch goes to pinned host memory on the recorder's side
+        stream while the next fetch is computed.  Returns the device batch (valid until the next fetch)."""
+        batch = self.fetch_amp_obs_demo_device(num_samples, seed) if device_sampling else self.fetch_amp_obs_demo(num_samples)
+        recorder.capture(batch)
+        return batch
 
     def _build_amp_obs_demo_buf(self, num_samples):
         self._amp_obs_demo_buf = torch.zeros((num_samples, self._num_amp_obs_steps, NUM_AMP_OBS_PER_STEP),

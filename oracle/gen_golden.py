@@ -2025,7 +2025,56 @@ def gen_angles_edge(seed=81, n=2560):
               ((np.abs(sy) < 1e-6) & (sy < 0)).sum(), (out["euler_roll"] > 6.28).sum(), (out["euler_yaw"] > 6.28).sum()))
 
 
-GENERATORS = {"angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+def gen_amp_demo(seed=11):
+    """HumanoidAMP.fetch_amp_obs_demo of the reference class (tasks/humanoid_amp.py:146-171) on the motion set of
+    motion.npz: numpy-seeded draws (replayed and stored), the tiling over the history steps, get_motion_state and
+    build_amp_observations, for two / three history steps and both root-observation frames."""
+    _install_gym_stubs()
+    import tempfile
+    sk = ref_shim.load("isaacgymenvs.tasks.amp.poselib.poselib.skeleton.skeleton3d")
+    ml = ref_shim.load("isaacgymenvs.tasks.amp.utils_amp.motion_lib")
+    hamp = ref_shim.load("isaacgymenvs.tasks.humanoid_amp")
+    tree = sk.SkeletonTree(AMP_NODE_NAMES, torch.tensor(AMP_PARENTS), torch.tensor(AMP_LOCAL_T, dtype=torch.float32))
+    specs = [(90, 30, 1.0), (61, 60, 3.0)]  # the motion set of gen_motion
+    with tempfile.TemporaryDirectory() as d:
+        entries = []
+        for i, (F, fps, wgt) in enumerate(specs):
+            _synth_motion(sk, tree, F, fps, seed + i).to_file(os.path.join(d, "m%d.npy" % i))
+            entries.append({"file": "m%d.npy" % i, "weight": wgt})
+        with open(os.path.join(d, "set.yaml"), "w") as f:
+            yaml.safe_dump({"motions": entries}, f)
+        cwd = os.getcwd()
+        os.chdir("/")
+        lib = ml.MotionLib(motion_file=os.path.join(d, "set.yaml"), num_dofs=28, key_body_ids=np.array([5, 8, 11, 14]),
+                           device="cpu")
+        os.chdir(cwd)
+    have = np.load(os.path.join(OUT, "motion.npz"), allow_pickle=False)
+    assert np.array_equal(have["motion_lengths"], lib._motion_lengths)
+    assert np.array_equal(have["m1_local_rotation"], lib._motions[1].local_rotation.numpy())
+
+    class Fake(hamp.HumanoidAMP):
+        def __init__(self):
+            pass
+
+    out, cases = {}, []
+    for c, (K, lro, dt, n, np_seed) in enumerate([(2, False, 0.0332, 160, 31), (3, True, 0.0166, 96, 32), (4, False, 0.05, 64, 33)]):
+        t = Fake()
+        t.device, t._motion_lib, t.dt, t._num_amp_obs_steps, t._local_root_obs = "cpu", lib, dt, K, lro
+        t._amp_obs_demo_buf, t.num_amp_obs = None, K * 105
+        np.random.seed(np_seed)
+        demo = t.fetch_amp_obs_demo(n)
+        np.random.seed(np_seed)
+        ids = lib.sample_motions(n)
+        times0 = lib.sample_time(ids)
+        out["c%d_ids" % c], out["c%d_times0" % c], out["c%d_demo" % c] = ids.copy(), times0.copy(), demo.numpy().copy()
+        cases.append(dict(K=K, local_root_obs=lro, dt=dt, n=n, np_seed=np_seed))
+        assert demo.shape == (n, K * 105)
+    out["meta"] = _meta(task="HumanoidAMP.fetch_amp_obs_demo", seed=seed, cases=cases)
+    np.savez_compressed(os.path.join(OUT, "amp_demo.npz"), **out)
+    print("amp_demo.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+GENERATORS = {"amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

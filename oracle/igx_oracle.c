@@ -1562,6 +1562,22 @@ int orc_motion_amp_obs(const igx_motion_tables *t, const int64_t *ids, const dou
     return 0;
 }
 
+/* HumanoidAMP.fetch_amp_obs_demo after its draws (tasks/humanoid_amp.py:156-171): ids tiled over the history
+ * steps, times0 + (-dt * k) in fp64, get_motion_state, build_amp_observations; out [n, num_steps * 105] */
+int orc_motion_amp_obs_steps(const igx_motion_tables *t, const int64_t *ids, const double *times, int64_t n,
+                             int32_t num_steps, double step_dt, int32_t local_root_obs, float *out)
+{
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < num_steps; ++k) {
+            float rp[3], rr[4], dp[28], rv[3], rav[3], dv[28], kp[12];
+            if (ids[i] < 0 || ids[i] >= t->num_motions) continue;
+            const double time = times[i] + (-step_dt * (double)k);
+            motion_state_one(t, ids[i], time, rp, rr, dp, rv, rav, dv, kp, NULL, NULL, NULL);
+            amp_obs_one(rp, rr, rv, rav, dp, 1, dv, 1, kp, local_root_obs, out + (i * num_steps + k) * 105);
+        }
+    return 0;
+}
+
 /* observation of environment e from the simulator tensors */
 static void amp_env_obs(const igx_amp_params *p, const igx_amp_buffers *b, int64_t e, float obs[105])
 {
@@ -1632,6 +1648,21 @@ int orc_motion_sample_flagged(const igx_motion_tables *t, const igx_motion_sampl
         motion_ids[e] = id;
         motion_times[e] = time;
         if (default_env_ids) default_env_ids[e] = denv;
+    }
+    return 0;
+}
+
+/* MotionLib.sample_motions / sample_time (tasks/amp/utils_amp/motion_lib.py:61-78) for n samples from the
+ * library's Philox stream: u0 picks the motion by cumulative weight, u1 is the phase */
+int orc_motion_sample(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int64_t *motion_ids,
+                      double *motion_times)
+{
+    for (int64_t e = 0; e < n; ++e) {
+        const double pick = (double)orc_philox_uniform(s->seed, s->rng_offset, e + s->env_offset, 0);
+        int64_t id = 0;
+        while (id < t->num_motions - 1 && !(pick < s->cdf[id])) ++id;
+        motion_ids[e] = id;
+        motion_times[e] = s->random_time ? (double)orc_philox_uniform(s->seed, s->rng_offset, e + s->env_offset, 1) * t->motion_length[id] : 0.0;
     }
     return 0;
 }

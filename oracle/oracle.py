@@ -176,6 +176,30 @@ def motion_amp_obs(tabs, ids, times, local_root_obs, out, out_rows=None, out_row
                                     C.c_int64(out_row_stride), C.c_int64(out_col_offset)) == 0
 
 
+def motion_amp_obs_steps(tabs, ids, times, num_steps, step_dt, local_root_obs):
+    """[n, num_steps * 105]: the batch of fetch_amp_obs_demo for drawn (ids, times0)."""
+    ids = np.ascontiguousarray(ids, np.int64)
+    times = np.ascontiguousarray(times, np.float64)
+    out = np.zeros((len(ids), num_steps * 105), np.float32)
+    t = motion_tables(tabs)
+    assert lib().orc_motion_amp_obs_steps(C.byref(t), C.c_void_p(ids.ctypes.data), C.c_void_p(times.ctypes.data),
+                                          C.c_int64(len(ids)), C.c_int32(int(num_steps)), C.c_double(float(step_dt)),
+                                          C.c_int32(int(local_root_obs)), C.c_void_p(out.ctypes.data)) == 0
+    return out
+
+
+def motion_sample(tabs, cdf, n, random_time, seed, rng_offset):
+    """(motion_ids, motion_times), each [n]: the library's device-side sample_motions + sample_time."""
+    cdf = np.ascontiguousarray(cdf, np.float64)
+    ids, times = np.zeros(n, np.int64), np.zeros(n, np.float64)
+    t = motion_tables(tabs)
+    s = _abi.MotionSampler(cdf=cdf.ctypes.data, random_time=int(random_time), ref_init_prob=1.0, seed=seed,
+                           rng_offset=rng_offset)
+    assert lib().orc_motion_sample(C.byref(t), C.byref(s), C.c_int64(n), C.c_void_p(ids.ctypes.data),
+                                   C.c_void_p(times.ctypes.data)) == 0
+    return ids, times
+
+
 def motion_sample_flagged(tabs, cdf, reset, random_time, seed, rng_offset, ref_init_prob=1.0):
     """Returns (env_ids, motion_ids, motion_times, default_env_ids), each [n]; holes are -1 / -1 / 0 / -1."""
     reset = np.ascontiguousarray(reset, np.int64)

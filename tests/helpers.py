@@ -381,15 +381,17 @@ def amp_joint_columns(kind):
     return cols
 
 
-def amp_obs_errors(x, ref):
+def amp_obs_errors(x, ref, copies_exact=True):
     """Per column group of an [n,105] AMP observation: max of |x - ref| / max(|ref|, natural scale), as an array
-    over the entries (so a caller may exempt entries) plus the group table."""
+    over the entries (so a caller may exempt entries) plus the group table.  copies_exact=False holds the copied
+    columns to the tolerance too (scale 1): for motion tables that were not taken from the recording but rebuilt by
+    the product's loader on this machine's host CPU, whose torch acos / sin may differ in the last bit."""
     x = np.asarray(x, np.float64).reshape(-1, 105)
     ref = np.asarray(ref, np.float64).reshape(-1, 105)
     err = np.zeros_like(ref)
     for name, a, b, kind in AMP_OBS_GROUPS:
         d = np.abs(x[:, a:b] - ref[:, a:b])
-        if kind == "exact":
+        if kind == "exact" and copies_exact:
             err[:, a:b] = np.where(d == 0, 0.0, np.inf)
             continue
         scale = 1.0
@@ -400,10 +402,10 @@ def amp_obs_errors(x, ref):
     return err
 
 
-def assert_amp_obs_close(x, ref, what="", rtol=RTOL, exempt=None, quiet=False):
+def assert_amp_obs_close(x, ref, what="", rtol=RTOL, exempt=None, quiet=False, copies_exact=True):
     """The 1e-5 bar per column group, each group at its own natural scale; prints the largest error of every group
     (in units of the tolerance' denominator).  `exempt`: boolean [n,105] of entries left out (knife-edge joints)."""
-    err = amp_obs_errors(x, ref)
+    err = amp_obs_errors(x, ref, copies_exact)
     if exempt is not None:
         err = np.where(exempt.reshape(err.shape), 0.0, err)
     worst = {name: (float(err[:, a:b].max()) if err.size else 0.0) for name, a, b, _ in AMP_OBS_GROUPS}

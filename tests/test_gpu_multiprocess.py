@@ -72,6 +72,6 @@ def test_bench_world_of_one_through_rccl_with_configs():
     assert d["rccl_ranks"] == 1 and d["config"]["collective_backend"] == "nccl" and d["collectives"]["barrier"] == "nccl"
     assert d["roofline"]["traffic"] is None  # the committed PMC figure belongs to the 2^20-env run only
     for name in ("humanoid_step", "allegro_post", "allegro_pre", "humanoid_amp_step", "motion_amp_obs_1024",
-                 "motion_amp_obs_1048576"):
+                 "motion_amp_obs_1048576", "amp_demo_fetch_device_sampling", "amp_demo_fetch_streamed_to_host"):
         assert d["configs"][name]["us"] > 0, name
     assert d["configs"]["humanoid_step"]["bytes_per_unit"] == 940 and "frac" in d["configs"]["humanoid_amp_step"]

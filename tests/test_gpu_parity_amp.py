@@ -102,6 +102,40 @@ def test_fused_motion_amp_obs_golden(motion):
     assert not b[:, 0].any()
 
 
+def test_fetch_amp_obs_demo_golden(motion):
+    """amp_demo.npz (the reference class's own fetch_amp_obs_demo) through igx_motion_amp_obs_steps on the
+    recording's tables: 1e-5 per group, copied columns bit for bit; equal to the checker's tiling bit for bit in
+    the frame arithmetic (same frames => same copied joint velocities)."""
+    _, tabs_np, _, tables = motion
+    g = H.load_golden("amp_demo")
+    for c, case in enumerate(g["meta"]["cases"]):
+        n, K = case["n"], case["K"]
+        out = torch.zeros(n, K * 105, device=DEV)
+        ops.motion_amp_obs_steps(tables, dev(g["c%d_ids" % c]), dev(g["c%d_times0" % c]), K, case["dt"],
+                                 case["local_root_obs"], out)
+        H.assert_amp_obs_close(host(out), g["c%d_demo" % c], what="fetch_amp_obs_demo case %d vs the recording" % c)
+        want = oracle.motion_amp_obs_steps(tabs_np, g["c%d_ids" % c], g["c%d_times0" % c], K, case["dt"], case["local_root_obs"])
+        H.assert_amp_obs_close(host(out), want, what="vs checker", quiet=True)
+        # one launch on n draws == the tiled lists through igx_motion_amp_obs, bit for bit
+        ids = np.tile(np.expand_dims(g["c%d_ids" % c], -1), [1, K]).flatten()
+        times = (np.expand_dims(g["c%d_times0" % c], -1) + (-case["dt"] * np.arange(0, K))).flatten()
+        tiled = torch.zeros(n * K, 105, device=DEV)
+        ops.motion_amp_obs(tables, dev(ids), dev(times), case["local_root_obs"], tiled)
+        assert torch.equal(out.view(-1, 105), tiled)
+
+
+def test_device_sampler_equals_the_checker(motion):
+    g, tabs_np, tabs_dev, tables = motion
+    cdf = np.cumsum(g["motion_weights"]) / np.sum(g["motion_weights"])
+    n = 100003
+    ids = torch.empty(n, dtype=torch.int64, device=DEV)
+    times = torch.empty(n, dtype=torch.float64, device=DEV)
+    for random_time in (True, False):
+        ops.motion_sample(tables, dev(cdf), ids, times, random_time=random_time, seed=77, rng_offset=5)
+        want = oracle.motion_sample(tabs_np, cdf, n, random_time, seed=77, rng_offset=5)
+        assert np.array_equal(host(ids), want[0]) and np.array_equal(host(times), want[1])
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 4097, 200000])
 def test_motion_state_vs_oracle(motion, n):
     _, tabs_np, _, tables = motion

@@ -42,6 +42,26 @@ def test_recorder_matches_per_step_host_copies(n, width, ring):
     rec.close()
 
 
+@pytest.mark.parametrize("n,width,ring,offset", [(1, 3, 1, 0), (1000, 210, 2, 0), (4097, 105, 3, 0), (333, 7, 2, 1)])
+def test_whole_row_recorder_matches_per_step_host_copies(n, width, ring, offset):
+    """columns=None: the buffer as it is, [steps, n, width] on the host (slabs whose size is not a multiple of 16
+    bytes, a source that is only 4-byte aligned, and more captures than ring slots)."""
+    steps = 7
+    rec = TrajectoryRecorder(n, width, None, steps, DEV, ring_slots=ring)
+    flat = torch.empty(n * width + offset, device=DEV)
+    buf = flat[offset:].view(n, width)
+    want = []
+    for t in range(steps):
+        buf.copy_(torch.randn(n, width, device=DEV))
+        rec.capture(buf)
+        want.append(buf.cpu().clone())
+    got = rec.finish()
+    assert got.shape == (steps, n, width) and torch.equal(got, torch.stack(want))
+    with pytest.raises(IgxError):
+        rec.capture(buf)
+    rec.close()
+
+
 def test_recorder_rejects_bad_arguments():
     with pytest.raises(IgxError):
         TrajectoryRecorder(8, 4, dict(x=4), 3, DEV)

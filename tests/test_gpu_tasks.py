@@ -480,6 +480,61 @@ def test_amp_demo_batches_stream_to_the_host(motion_lib):
     assert len({float(w.sum()) for w in want}) == steps    # every batch was a new sample
 
 
+def test_amp_fetch_demo_on_the_reference_recording(motion_lib):
+    """amp_demo.npz: the reference class's own fetch_amp_obs_demo.  Seeding numpy as the recording did, the
+    product class (own loader, own tables) draws the same samples and its one-launch fetch gives the recorded batch
+    (1e-5 per group)."""
+    g = H.load_golden("amp_demo")
+    for c, case in enumerate(g["meta"]["cases"]):
+        task = _amp_task(motion_lib, 64, numAMPObsSteps=case["K"], localRootObs=case["local_root_obs"])
+        task.dt = case["dt"]
+        np.random.seed(case["np_seed"])
+        demo = task.fetch_amp_obs_demo(case["n"])
+        assert demo.shape == (case["n"], case["K"] * 105)
+        # the class's tables are rebuilt from the raw motions by the product's loader on THIS machine's host CPU
+        # (finite differences through torch's acos / sin): the copied joint velocities can differ from the
+        # recording's in the last bit, so they are held to 1e-5 here; with the recording's own tables they are
+        # bit-exact (tests/test_gpu_parity_amp.py::test_fetch_amp_obs_demo_golden)
+        H.assert_amp_obs_close(host(demo), g["c%d_demo" % c], what="fetch_amp_obs_demo case %d" % c, copies_exact=False)
+
+
+def test_amp_fetch_demo_with_device_sampling(motion_lib):
+    """fetch_amp_obs_demo_device: the draws are the CPU checker's restatement of the device sampler bit for bit,
+    the batch is what the host path computes for those draws, and successive fetches differ."""
+    g = H.load_golden("motion")
+    tabs = H.motion_tabs_from_golden(g)
+    cdf = np.cumsum(g["motion_weights"]) / np.sum(g["motion_weights"])
+    n = 1024
+    task = _amp_task(motion_lib, 64)
+    a = task.fetch_amp_obs_demo_device(n, seed=21).clone()
+    ids, times = (t.clone() for t in task._demo_draws)
+    want_ids, want_times = oracle.motion_sample(tabs, cdf, n, True, seed=21, rng_offset=1)
+    assert np.array_equal(host(ids), want_ids) and np.array_equal(host(times), want_times)
+    via_host = torch.zeros(n, 2, 105, device=DEV)
+    motion_lib.get_amp_obs_steps(host(ids), host(times), 2, task.dt, False, via_host)
+    assert torch.equal(a, via_host.view(n, 210))
+    b = task.fetch_amp_obs_demo_device(n, seed=21)
+    assert not torch.equal(a, b)                                   # the second fetch drew again
+    assert np.array_equal(host(task._demo_draws[0]), oracle.motion_sample(tabs, cdf, n, True, seed=21, rng_offset=2)[0])
+
+
+@pytest.mark.parametrize("device_sampling", [False, True])
+def test_amp_demo_batches_stream_to_the_host_as_whole_rows(motion_lib, device_sampling):
+    """stream_amp_obs_demo: every fetched [n, 210] batch lands in pinned host memory as it is (whole-row
+    recorder, one contiguous copy per fetch on the side stream), bit for bit, while the next fetch runs."""
+    from isaacgym_amd.recorder import TrajectoryRecorder
+    n, fetches = 512, 11
+    task = _amp_task(motion_lib, 64)
+    rec = TrajectoryRecorder(n, task.get_num_amp_obs(), None, fetches, DEV, ring_slots=2)
+    np.random.seed(5)
+    want = [task.stream_amp_obs_demo(rec, n, device_sampling=device_sampling, seed=3).clone() for _ in range(fetches)]
+    got = rec.finish()
+    rec.close()
+    assert got.shape == (fetches, n, 210)
+    assert torch.equal(got, torch.stack(want).cpu())
+    assert len({float(w.sum()) for w in want}) == fetches          # every batch was a new sample
+
+
 # ------------------------------------------------------------------------- random object forces
 @pytest.mark.parametrize("name,nact", [("AllegroHand", 16), ("ShadowHand", 20)])
 def test_hand_random_forces_through_the_class(name, nact):

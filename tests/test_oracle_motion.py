@@ -88,3 +88,41 @@ def test_holes_are_skipped_by_motion_state_and_reset():
     obs = np.full((5, 105), 9.0, np.float32)
     oracle.motion_amp_obs(tabs, ids, times, 0, obs)
     assert (obs[[1, 3]] == 9.0).all() and (obs[[0, 2, 4]] != 9.0).any(axis=1).all()
+
+
+def test_fetch_amp_obs_demo_matches_reference():
+    """amp_demo.npz: the reference class's own fetch_amp_obs_demo (numpy-seeded draws, tiling over the history
+    steps in fp64, get_motion_state, build_amp_observations) for 2 / 3 / 4 history steps."""
+    g = H.load_golden("amp_demo")
+    tabs = H.motion_tabs_from_golden(H.load_golden("motion"))
+    for c, case in enumerate(g["meta"]["cases"]):
+        got = oracle.motion_amp_obs_steps(tabs, g["c%d_ids" % c], g["c%d_times0" % c], case["K"], case["dt"],
+                                          case["local_root_obs"])
+        H.assert_amp_obs_close(got, g["c%d_demo" % c], what="fetch_amp_obs_demo case %d" % c)
+        # the fused tiling is the tiling of the reference's host code, bit for bit
+        K = case["K"]
+        ids = np.tile(np.expand_dims(g["c%d_ids" % c], -1), [1, K]).flatten()
+        times = (np.expand_dims(g["c%d_times0" % c], -1) + (-case["dt"] * np.arange(0, K))).flatten()
+        want = np.zeros((len(ids), 105), np.float32)
+        oracle.motion_amp_obs(tabs, ids, times, case["local_root_obs"], want)
+        assert np.array_equal(got.view(np.uint32), want.reshape(got.shape).view(np.uint32))
+
+
+def test_device_sampler_for_demo_batches_follows_the_distributions():
+    g = H.load_golden("motion")
+    tabs = H.motion_tabs_from_golden(g)
+    cdf = np.cumsum(g["motion_weights"]) / np.sum(g["motion_weights"])
+    n = 200000
+    ids, times = oracle.motion_sample(tabs, cdf, n, True, seed=9, rng_offset=3)
+    assert ids.min() == 0 and ids.max() == 1
+    assert abs((ids == 1).mean() - g["motion_weights"][1]) < 5e-3       # motion chosen by weight
+    phase = times / tabs["motion_length"][ids]
+    assert 0.0 <= phase.min() and phase.max() < 1.0 and abs(phase.mean() - 0.5) < 5e-3   # uniform phase
+    again = oracle.motion_sample(tabs, cdf, n, True, seed=9, rng_offset=3)
+    assert np.array_equal(again[0], ids) and np.array_equal(again[1], times)
+    other = oracle.motion_sample(tabs, cdf, n, True, seed=9, rng_offset=4)
+    assert not np.array_equal(other[1], times)
+    # the flagged sampler with every flag set draws the same numbers
+    e, fi, ft, _ = oracle.motion_sample_flagged(tabs, cdf, np.ones(n, np.int64), True, 9, 3)
+    assert np.array_equal(fi, ids) and np.array_equal(ft, times) and np.array_equal(e, np.arange(n))
+    assert not oracle.motion_sample(tabs, cdf, 100, False, seed=9, rng_offset=3)[1].any()   # stateInit Start: time 0
