@@ -126,8 +126,11 @@ __device__ __forceinline__ void euler_roll_yaw(f4 q, float &roll, float &yaw)
 __device__ __forceinline__ float unscale(float x, float lo, float hi) { return (2.0f * x - hi - lo) / (hi - lo); }
 // :234-236 scale
 __device__ __forceinline__ float scale(float x, float lo, float hi) { return 0.5f * (x + 1.0f) * (hi - lo) + lo; }
-// :228-230 tensor_clamp
-__device__ __forceinline__ float tensor_clamp(float t, float lo, float hi) { return fmaxf(fminf(t, hi), lo); }
+// torch.min / torch.max of two tensors: a NaN on either side gives NaN (fminf / fmaxf would drop it)
+__device__ __forceinline__ float torch_min(float a, float b) { return (a != a || b != b) ? a + b : (b < a ? b : a); }
+__device__ __forceinline__ float torch_max(float a, float b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
+// :228-230 tensor_clamp = torch.max(torch.min(t, hi), lo): a NaN target stays NaN
+__device__ __forceinline__ float tensor_clamp(float t, float lo, float hi) { return torch_max(torch_min(t, hi), lo); }
 
 // :65-67 normalize applied to a quaternion (quat_unit, :113-115)
 __device__ __forceinline__ f4 quat_unit(f4 q)

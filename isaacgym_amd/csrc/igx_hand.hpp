@@ -93,7 +93,8 @@ __device__ __forceinline__ float hand_reward(const P &p, const float (&obj)[13],
 {
     int64_t prog = f.prog + 1;
     const float goal_dist = norm3(f3{obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2]});
-    const float cc = fminf(norm3(f3{qd.x, qd.y, qd.z}), 1.0f);
+    const float cn = norm3(f3{qd.x, qd.y, qd.z});
+    const float cc = cn > 1.0f ? 1.0f : cn;  // torch.clamp(max=1.0): a NaN stays NaN
     const float rot_dist = 2.0f * asinf(cc);
     const float dist_rew = goal_dist * p.dist_reward_scale;
     const float rot_rew = 1.0f / (fabsf(rot_dist) + p.rot_eps) * p.rot_reward_scale;

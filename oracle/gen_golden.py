@@ -107,7 +107,7 @@ def _replay_uniforms(state, shapes):
 
 
 # --------------------------------------------------------------------------
-def gen_cartpole(seed=0, N=4096, T=4):
+def gen_cartpole(seed=0, N=4096, T=4, name="cartpole", poison=False):
     _install_gym_stubs()
     mod = ref_shim.load("isaacgymenvs.tasks.cartpole")
     cfg = _cfg("Cartpole")
@@ -142,6 +142,11 @@ def gen_cartpole(seed=0, N=4096, T=4):
         ds[:, :, 1] = torch.randn(N, 2, generator=g)
         ds[0, 0, 0] = 3.0       # exactly resetDist: not > 3.0
         ds[1, 1, 0] = math.pi / 2  # float32(pi/2): not > float32(pi/2)
+        if poison:  # non-finite joint state in a few environments, other ones every step
+            o = 16 + 8 * step
+            for i, (j, c, v) in enumerate([(0, 0, "nan"), (1, 0, "nan"), (0, 1, "nan"), (1, 1, "nan"), (0, 0, "inf"),
+                                           (1, 0, "-inf"), (0, 1, "inf"), (1, 1, "-inf")]):
+                ds[o + i, j, c] = float(v)
         t.dof_state.copy_(ds.view(N * 2, 2))
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
         ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
@@ -162,8 +167,8 @@ def gen_cartpole(seed=0, N=4096, T=4):
     out.update(init)
     out["meta"] = _meta(task="Cartpole", N=N, T=T, seed=seed, reset_dist=t.reset_dist,
                         max_episode_length=t.max_episode_length)
-    np.savez_compressed(os.path.join(OUT, "cartpole.npz"), **out)
-    print("cartpole.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
 def gen_cartpole_sample(seed=5, N=257, T=6):
@@ -320,8 +325,33 @@ def _loco_inputs(t, N, D, S, g, z_mean, z_std, with_force):
         t.dof_force_tensor = torch.randn(N, D, generator=g) * 30
 
 
+def _poison_loco(t, step, humanoid):
+    """Non-finite simulator state (a physics blow-up) in a few environments, other ones every step: what the
+    reference's own arithmetic makes of NaN / +-Inf (torch's comparisons, where, clamp, atan2) is the contract."""
+    nan, inf = float("nan"), float("inf")
+    o = 10 + 16 * step
+    r, ds = t.root_states, t.dof_state.view(t.num_envs, t.num_dof, 2)
+    r[o + 0, 0] = nan            # position x
+    r[o + 1, 6] = nan            # quaternion w
+    r[o + 2, 2] = inf            # height
+    r[o + 3, 2] = -inf           # height below everything: termination
+    r[o + 4, 7] = inf            # linear velocity
+    r[o + 5, 11] = -inf          # angular velocity
+    ds[o + 6, 3, 0] = nan        # a joint position
+    ds[o + 7, 2, 1] = -inf       # a joint velocity
+    t.actions[o + 8, 1] = nan
+    t.actions[o + 9, 0] = inf
+    t.vec_sensor_tensor[o + 10, 5] = nan
+    r[o + 11, 3:7] = 0.0         # a zero quaternion
+    r[o + 12, 3:7] = torch.tensor([nan, nan, nan, nan])
+    r[o + 13, 0] = inf           # infinitely far from the target
+    if humanoid:
+        t.dof_force_tensor[o + 14, 4] = nan
+        t.dof_force_tensor[o + 15, 0] = inf
+
+
 def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_over=None, dt=None, targets=None,
-              start_rotation=None):
+              start_rotation=None, poison=False):
     """env_over / dt / targets / start_rotation: non-default values, so that a recording also pins how every
     parameter enters the arithmetic (the default files only exercise the YAML defaults)."""
     _install_gym_stubs()
@@ -377,6 +407,8 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_o
     torch.manual_seed(seed + 100)
     for step in range(T):
         _loco_inputs(t, N, D, S, g, z_mean, z_std, humanoid)
+        if poison:
+            _poison_loco(t, step, humanoid)
         rec["in_root"].append(t.root_states.numpy().copy())
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
         rec["in_sensors"].append(t.vec_sensor_tensor.numpy().copy())
@@ -629,8 +661,28 @@ def gen_loco_alt():
               targets=[120.0, -80.0, 0.0], start_rotation=[0.0, 0.3, 0.0, 0.95])
 
 
+def gen_loco_nonfinite():
+    """Ant and Humanoid with NaN / +-Inf in the simulator tensors of some environments."""
+    _gen_loco("ant_nonfinite", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, 91, 96, 4, poison=True)
+    _gen_loco("humanoid_nonfinite", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, 92, 96, 4, poison=True)
+
+
 # --------------------------------------------------------------------------
-def gen_math(seed=3, n=1536):
+def _poison_rows(x):
+    """NaN / +Inf / -Inf, one entry per row, in rows 100 ... of a [n] or [n, k] input (in place; returns x)."""
+    vals = [float("nan"), float("inf"), -float("inf")]
+    if x.dim() == 1:
+        for i in range(6):
+            x[100 + i] = vals[i % 3]
+    else:
+        k = x.shape[1]
+        for i in range(3 * k):
+            x[100 + i, i % k] = vals[(i // k) % 3]
+        x[100 + 3 * k] = float("nan")
+    return x
+
+
+def gen_math(seed=3, n=1536, name="math", P=lambda x: x):
     """torch_jit_utils functions on random inputs plus the edge cases of each."""
     _install_gym_stubs()
     tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
@@ -645,6 +697,7 @@ def gen_math(seed=3, n=1536):
     qb[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])
     v = torch.randn(n, 3, generator=g)
     v[1] = 0.0
+    P(qa), P(qb), P(v)
     out = {"qa": qa, "qb": qb, "v": v}
     out["quat_mul"] = tj.quat_mul(qa, qb)
     out["quat_conjugate"] = tj.quat_conjugate(qa)
@@ -662,16 +715,19 @@ def gen_math(seed=3, n=1536):
     t[60:90] = torch.rand(30, 1, generator=g) * 3 - 1.5
     t[0] = 0.0
     t[1] = 1.0
+    P(t)
     out.update(slerp_q0=s0, slerp_q1=s1, slerp_t=t, slerp=tj.slerp(s0, s1, t))
 
     angle = (torch.rand(n, generator=g) * 2 - 1) * 4.0
     axis = torch.randn(n, 3, generator=g)
     angle[0] = 0.0
     axis[1] = 0.0  # zero-norm axis: clamp(min=1e-9) path
+    P(angle), P(axis)
     out.update(angle=angle, axis=axis, quat_from_angle_axis=tj.quat_from_angle_axis(angle, axis))
 
     x = (torch.rand(n, generator=g) * 2 - 1) * 10.0
     x[:5] = torch.tensor([0.0, math.pi, -math.pi, 2 * math.pi, -0.0])
+    P(x)
     out.update(na_x=x, normalize_angle=tj.normalize_angle(x))
 
     qe = qa.clone()
@@ -684,6 +740,7 @@ def gen_math(seed=3, n=1536):
     e[0] = 0.0                                   # 0 / 0 lanes, masked by where
     e[1] = torch.tensor([1e-7, 0.0, 0.0])
     e[2] = torch.tensor([4.0, 0.0, 0.0])         # angle > pi wraps
+    P(e)
     out.update(e=e, exp_map_to_quat=tj.exp_map_to_quat(e))
 
     out["quat_to_tan_norm"] = tj.quat_to_tan_norm(qa)
@@ -692,16 +749,16 @@ def gen_math(seed=3, n=1536):
     d = 16
     lo = -torch.rand(d, generator=g) - 0.2
     hi = torch.rand(d, generator=g) + 0.3
-    xs = torch.randn(n, d, generator=g)
+    xs = P(torch.randn(n, d, generator=g))
     out.update(aff_x=xs, aff_lo=lo, aff_hi=hi, scale=tj.scale(xs, lo, hi), unscale=tj.unscale(xs, lo, hi),
                tensor_clamp=tj.tensor_clamp(xs, lo, hi))
     out = {k: v.numpy() for k, v in out.items()}
     out["meta"] = _meta(task="torch_jit_utils", n=n, seed=seed)
-    np.savez_compressed(os.path.join(OUT, "math.npz"), **out)
-    print("math.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-def gen_math2(seed=4, n=1024):
+def gen_math2(seed=4, n=1024, name="math2", P=lambda x: x):
     """The rest of torch_jit_utils: every function of the module that works on [n, k] rows."""
     _install_gym_stubs()
     tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
@@ -719,10 +776,12 @@ def gen_math2(seed=4, n=1024):
     v = torch.randn(n, 3, generator=g)
     v2 = torch.randn(n, 3, generator=g)
     v[4] = 0.0
+    P(qa), P(qb), P(v), P(v2)
     out = {"qa": qa, "qb": qb, "v": v, "v2": v2}
 
     raw4 = torch.randn(n, 4, generator=g) * 3.0
     raw4[0] = 0.0                                               # clamp(min=1e-9) path
+    P(raw4)
     out.update(raw4=raw4, normalize3=tj.normalize(v), normalize4=tj.normalize(raw4), quat_unit=tj.quat_unit(raw4))
     out["quat_apply"] = tj.quat_apply(qa, v)
     qi, ti = tj.tf_inverse(qa, v)
@@ -740,6 +799,7 @@ def gen_math2(seed=4, n=1024):
     ep = (torch.rand(n, generator=g) * 2 - 1) * math.pi
     ey = (torch.rand(n, generator=g) * 2 - 1) * math.pi
     er[0] = ep[0] = ey[0] = 0.0
+    P(er), P(ep), P(ey)
     out.update(er=er, ep=ep, ey=ey, quat_from_euler_xyz=tj.quat_from_euler_xyz(er, ep, ey),
                euler_xyz_to_exp_map=tj.euler_xyz_to_exp_map(er, ep, ey))
 
@@ -755,12 +815,13 @@ def gen_math2(seed=4, n=1024):
     to_target[5] = 0.0
     vec0 = torch.randn(n, 3, generator=g)
     vec1 = torch.randn(n, 3, generator=g)
+    P(isr), P(to_target), P(vec0), P(vec1)
     for idx in (2, 1):
         tq, upp, hp, upv, hv = tj.compute_heading_and_up(qa, isr, to_target, vec0, vec1, idx)
         out.update({"hu%d_torso_quat" % idx: tq, "hu%d_up_proj" % idx: upp, "hu%d_heading_proj" % idx: hp,
                     "hu%d_up_vec" % idx: upv, "hu%d_heading_vec" % idx: hv})
     out.update(isr=isr, to_target=to_target, vec0=vec0, vec1=vec1)
-    targets = torch.randn(n, 3, generator=g) * 100.0
+    targets = P(torch.randn(n, 3, generator=g) * 100.0)
     vl, al, rr, pp, yy, att = tj.compute_rot(qb, v, v2, targets, to_target)
     out.update(targets=targets, rot_vel_loc=vl, rot_angvel_loc=al, rot_roll=rr, rot_pitch=pp, rot_yaw=yy,
                rot_angle_to_target=att)
@@ -770,7 +831,7 @@ def gen_math2(seed=4, n=1024):
     d = 12
     lo = -torch.rand(d, generator=g) - 0.2
     hi = torch.rand(d, generator=g) + 0.3
-    xs = torch.randn(n, d, generator=g)
+    xs = P(torch.randn(n, d, generator=g))
     out.update(aff_x=xs, aff_lo=lo, aff_hi=hi, scale_transform=tj.scale_transform(xs, lo, hi),
                unscale_transform=tj.unscale_transform(xs, lo, hi), saturate=tj.saturate(xs, lo, hi))
 
@@ -781,7 +842,7 @@ def gen_math2(seed=4, n=1024):
     da[30:40] = da[30:40] * 1.5      # not unit: the clamp(max=1) branch
     out.update(diff_a=da, diff_b=db, quat_diff_rad=tj.quat_diff_rad(da, db))
 
-    pose = torch.cat([torch.randn(n, 3, generator=g), qb], dim=-1)
+    pose = P(torch.cat([torch.randn(n, 3, generator=g), qb], dim=-1))
     out.update(pose=pose, local_to_world_space=tj.local_to_world_space(v, pose))
 
     qe = qa.clone()
@@ -792,14 +853,15 @@ def gen_math2(seed=4, n=1024):
     e[0] = 0.0
     e[1] = torch.tensor([1e-7, 0.0, 0.0])
     e[2] = torch.tensor([4.0, 0.0, 0.0])
+    P(e)
     ang2, axs2 = tj.exp_map_to_angle_axis(e)
     out.update(e=e, e2aa_angle=ang2, e2aa_axis=axs2)
     out.update(calc_heading=tj.calc_heading(qa), calc_heading_quat=tj.calc_heading_quat(qa))
 
     out = {k: v.numpy() for k, v in out.items()}
     out["meta"] = _meta(task="torch_jit_utils (remaining functions)", n=n, seed=seed)
-    np.savez_compressed(os.path.join(OUT, "math2.npz"), **out)
-    print("math2.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
 # --------------------------------------------------------------------------
@@ -826,7 +888,7 @@ def success_threshold_c(tol):
 
 def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, object_type="block",
                  max_consecutive_successes=0, use_relative_control=False, act_moving_average=None,
-                 force_scale=None, force_prob_range=(0.001, 0.1)):
+                 force_scale=None, force_prob_range=(0.001, 0.1), poison=False):
     _install_gym_stubs()
     mod = ref_shim.load("isaacgymenvs.tasks.allegro_hand")
     tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
@@ -942,6 +1004,9 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
         if step == 1:
             t.progress_buf[:4] = torch.tensor([596, 597, 598, 599])
         actions = torch.rand(N, D, generator=g) * 2 - 1
+        if poison:  # a policy that blew up in a few environments
+            o = 40 + 10 * step
+            actions[o, 2], actions[o + 1, 0], actions[o + 1, 5] = float("nan"), float("inf"), -float("inf")
         rec["actions"].append(actions.numpy().copy())
         env_ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
         goal_ids = t.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
@@ -999,6 +1064,17 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
         q[4:8] = t.goal_states[4:8, 3:7]
         obj[:, 3:7] = q
         obj[:, 7:13] = torch.randn(N, 6, generator=g)
+        if poison:  # a simulation that blew up in a few other environments
+            o = 40 + 10 * step
+            nan, inf = float("nan"), float("inf")
+            obj[o + 2, 0] = nan              # object position
+            obj[o + 3, 3:7] = nan            # object rotation
+            obj[o + 4, 1] = inf              # infinitely far from the goal: a fall
+            obj[o + 5, 9] = -inf             # object velocity
+            t.dof_state.view(N, D, 2)[o + 6, 3, 0] = nan
+            t.dof_state.view(N, D, 2)[o + 7, 1, 1] = inf
+            t.dof_force_tensor[o + 8, 2] = nan
+            obj[o + 9, 3:7] = 0.0            # a zero quaternion
         t.root_state_tensor[t.object_indices] = obj
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
         rec["in_dof_force"].append(t.dof_force_tensor.numpy().copy())
@@ -1393,9 +1469,10 @@ def gen_motion(seed=11):
     # every switch the other way: root observation in the heading frame, a deeper history, other thresholds
     _gen_amp_task(lib, hamp, seed + 7, N=64, K=3, name="amp_alt",
                   over=dict(localRootObs=True, terminationHeight=0.62, episodeLength=150))
+    _gen_amp_task(lib, hamp, seed + 9, N=64, K=2, name="amp_nonfinite", poison=True)
 
 
-def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None):
+def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None, poison=False):
     """HumanoidAMP.post_physics_step / reset_idx of the reference task class on
     synthetic simulator tensors, with the reference MotionLib built above."""
     cfg = _cfg("HumanoidAMP")
@@ -1474,6 +1551,18 @@ def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None):
         cf[4] = -3.0                                            # negative components never count
         cf[5, 3, 1] = 0.1                                       # exactly 0.1: not > 0.1
         t._contact_forces.copy_(cf)
+        if poison:  # non-finite simulator state in a few environments
+            nan, inf = float("nan"), float("inf")
+            t._root_states[40, 0], t._root_states[41, 6], t._root_states[42, 2] = nan, nan, inf
+            t._root_states[43, 8], t._root_states[44, 3:7] = -inf, 0.0
+            t._dof_state.view(N, 28, 2)[45, 1, 0] = nan           # inside a 3-dof joint
+            t._dof_state.view(N, 28, 2)[46, 9, 0] = inf           # a hinge
+            t._dof_state.view(N, 28, 2)[47, 4, 1] = nan           # a joint velocity
+            t._rigid_body_state.view(N, 15, 13)[48, 3, 2] = nan   # a body height: not < the termination height
+            t._rigid_body_state.view(N, 15, 13)[49, 3, 2] = -inf
+            t._rigid_body_state.view(N, 15, 13)[50, 5, 0] = nan   # a key body
+            t._contact_forces[51, 2, 0], t._contact_forces[52, 2, 1] = nan, inf
+            t._contact_forces[49, 2, 1] = inf                     # together with the body at -inf: a fall
 
     keys = ["in_root", "in_dof_state", "in_rigid_body_state", "in_contact_forces", "obs", "amp_obs", "rew", "reset",
             "terminate", "progress"]
@@ -2074,7 +2163,19 @@ def gen_amp_demo(seed=11):
     print("amp_demo.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+def gen_math_nonfinite():
+    """Every torch_jit_utils function on inputs with NaN / +-Inf rows (rows 100 ... of each input)."""
+    gen_math(seed=13, n=192, name="math_nonfinite", P=_poison_rows)
+    gen_math2(seed=14, n=192, name="math2_nonfinite", P=_poison_rows)
+
+
+def gen_nonfinite_tasks():
+    """Cartpole and AllegroHand on non-finite simulator state / actions (HumanoidAMP's comes out of gen_motion)."""
+    gen_cartpole(seed=93, N=128, T=4, name="cartpole_nonfinite", poison=True)
+    _gen_allegro("nonfinite", N=96, T=4, seed=94, poison=True)
+
+
+GENERATORS = {"nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -165,6 +165,10 @@ static void quat_rotate_s(const float q[4], const float v[3], float o[3], int in
     }
 }
 
+/* torch.min / torch.max of two tensors: a NaN on either side gives NaN (fminf / fmaxf would drop it) */
+static float torch_min(float a, float b) { return (a != a || b != b) ? a + b : (b < a ? b : a); }
+static float torch_max(float a, float b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
+
 /* torch.remainder(x, float32(2*pi)) */
 static float remainder_2pi(float x)
 {
@@ -311,8 +315,8 @@ int orc_loco_reset(const igx_loco_params *p, const igx_loco_buffers *b, const in
             float pos = 0.4f * up + (-0.2f);
             float vel = 0.2f * uv + (-0.1f);
             float t = b->initial_dof_pos[e * D + j] + pos;
-            t = fminf(t, p->dof_limits_upper[j]);
-            t = fmaxf(t, p->dof_limits_lower[j]);
+            t = torch_min(t, p->dof_limits_upper[j]);
+            t = torch_max(t, p->dof_limits_lower[j]);
             ds[2 * j] = t;
             ds[2 * j + 1] = vel;
         }
@@ -361,8 +365,8 @@ static int loco_step(const igx_loco_params *p, const igx_loco_buffers *b, int64_
                 float vel = 0.2f * uv + (-0.1f);
                 float t = b->initial_dof_pos[e * D + j] + pos;
                 /* tensor_clamp: max(min(t, hi), lo) */
-                t = fminf(t, p->dof_limits_upper[j]);
-                t = fmaxf(t, p->dof_limits_lower[j]);
+                t = torch_min(t, p->dof_limits_upper[j]);
+                t = torch_max(t, p->dof_limits_lower[j]);
                 ds[2 * j] = t;
                 ds[2 * j + 1] = vel;
             }
@@ -632,7 +636,7 @@ int orc_unscale(const float *x, const float *lo, const float *hi, float *o, int6
 }
 int orc_tensor_clamp(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
 {
-    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); o[i] = fmaxf(fminf(x[i], hi[c]), lo[c]); }
+    for (int64_t i = 0; i < n * d; ++i) { int c = (int)(i % d); o[i] = torch_max(torch_min(x[i], hi[c]), lo[c]); }
     return 0;
 }
 int orc_quat_from_angle_axis(const float *angle, const float *axis, float *o, int64_t n)
@@ -1030,11 +1034,11 @@ int orc_allegro_pre_physics(const igx_allegro_params *p, const igx_allegro_buffe
             }
             if (p->use_relative_control) {
                 c = b->prev_targets[e * D + j] + p->dof_speed_scale_dt * a;
-                c = fmaxf(fminf(c, hi), lo);
+                c = torch_max(torch_min(c, hi), lo);
             } else {
                 c = 0.5f * (a + 1.0f) * (hi - lo) + lo;
                 c = p->act_moving_average * c + p->one_minus_act_moving_average * b->prev_targets[e * D + j];
-                c = fmaxf(fminf(c, hi), lo);
+                c = torch_max(torch_min(c, hi), lo);
             }
             b->cur_targets[e * D + j] = c;
             b->prev_targets[e * D + j] = c;
@@ -1101,7 +1105,7 @@ static int allegro_post(const igx_allegro_params *p, const igx_allegro_buffers *
         float dpos[3] = { obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2] };
         float goal_dist = norm3(dpos);
         float cn = norm3(qd);
-        float cc = fminf(cn, 1.0f);
+        float cc = cn > 1.0f ? 1.0f : cn; /* torch.clamp(max=1.0): a NaN stays NaN */
         float rot_dist = 2.0f * asinf(cc);
         float dist_rew = goal_dist * p->dist_reward_scale;
         float rot_rew = 1.0f / (fabsf(rot_dist) + p->rot_eps) * p->rot_reward_scale;
@@ -1259,11 +1263,11 @@ int orc_shadow_pre_physics(const igx_shadow_params *p, const igx_shadow_buffers 
             }
             if (p->use_relative_control) {
                 c = b->prev_targets[e * D + j] + p->dof_speed_scale_dt * x;
-                c = fmaxf(fminf(c, hi), lo);
+                c = torch_max(torch_min(c, hi), lo);
             } else {
                 c = 0.5f * (x + 1.0f) * (hi - lo) + lo;
                 c = p->act_moving_average * c + p->one_minus_act_moving_average * b->prev_targets[e * D + j];
-                c = fmaxf(fminf(c, hi), lo);
+                c = torch_max(torch_min(c, hi), lo);
             }
             b->cur_targets[e * D + j] = c;
             b->prev_targets[e * D + j] = c;
@@ -1337,7 +1341,8 @@ static int shadow_post(const igx_shadow_params *p, const igx_shadow_buffers *b, 
 
         float dpos[3] = { obj[0] - goal[0], obj[1] - goal[1], obj[2] - goal[2] };
         float goal_dist = norm3(dpos);
-        float cc = fminf(norm3(qd), 1.0f);
+        float cn = norm3(qd);
+        float cc = cn > 1.0f ? 1.0f : cn; /* torch.clamp(max=1.0): a NaN stays NaN */
         float rot_dist = 2.0f * asinf(cc);
         float dist_rew = goal_dist * p->dist_reward_scale;
         float rot_rew = 1.0f / (fabsf(rot_dist) + p->rot_eps) * p->rot_reward_scale;
@@ -2061,8 +2066,8 @@ int orc_humanoid_imitate_step(const igx_humanoid_imitate_params *p, const igx_hu
                 float up = draw(b->rand, e, 2 * D, j, p->seed, p->rng_offset, p->env_offset);
                 float uv = draw(b->rand, e, 2 * D, D + j, p->seed, p->rng_offset, p->env_offset);
                 float t = b->initial_dof_pos[e * D + j] + (0.4f * up + (-0.2f));
-                t = fminf(t, p->dof_limits_upper[j]);
-                t = fmaxf(t, p->dof_limits_lower[j]);
+                t = torch_min(t, p->dof_limits_upper[j]);
+                t = torch_max(t, p->dof_limits_lower[j]);
                 ds[2 * j] = t;
                 ds[2 * j + 1] = 0.2f * uv + (-0.1f);
             }

@@ -26,9 +26,10 @@ def _call(name, args):
     return fn(*args)
 
 
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
 @pytest.mark.parametrize("name,ins,outk,exact,scale", ROWWISE)
-def test_rowwise_golden(name, ins, outk, exact, scale):
-    g = H.load_golden("math")
+def test_rowwise_golden(name, ins, outk, exact, scale, fixture):
+    g = H.load_golden(fixture)
     got = _call(name, [_dev(g[k]) for k in ins]).cpu().numpy()
     ref = g[outk]
     assert got.shape == ref.shape
@@ -40,9 +41,10 @@ def test_rowwise_golden(name, ins, outk, exact, scale):
         H.assert_close(got, ref, scale=scale, what=name)
 
 
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
 @pytest.mark.parametrize("name", AFFINE)
-def test_affine_golden(name):
-    g = H.load_golden("math")
+def test_affine_golden(name, fixture):
+    g = H.load_golden(fixture)
     got = getattr(tj, name)(_dev(g["aff_x"]), _dev(g["aff_lo"]), _dev(g["aff_hi"])).cpu().numpy()
     assert H.bit_equal_fraction(got, g[name]) == 1.0
 
@@ -97,10 +99,11 @@ def test_shapes_follow_the_reference():
     assert tj.quat_to_tan_norm(q[:, 0]).shape == (5, 6)
 
 
+@pytest.mark.parametrize("fixture", ["math2", "math2_nonfinite"])
 @pytest.mark.parametrize("case", MULTI, ids=[c[0] for c in MULTI])
-def test_remaining_functions_golden(case):
+def test_remaining_functions_golden(case, fixture):
     cid, fn, args, outk, classes, scale = case
-    g = H.load_golden("math2")
+    g = H.load_golden(fixture)
     got = getattr(tj, fn)(*[_dev(g[a]) if isinstance(a, str) else a for a in args])
     got = tuple(t.cpu().numpy() for t in (got if isinstance(got, tuple) else (got,)))
     check_outputs(H, got, g, outk, classes, scale, cid)

@@ -16,7 +16,7 @@ def _to_dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample"])
+@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample", "cartpole_nonfinite"])
 def test_cartpole_golden(name):
     g = H.load_golden(name)
     m = g["meta"]
@@ -131,6 +131,16 @@ def test_ant_golden_with_every_parameter_changed():
 
 def test_humanoid_golden_with_every_parameter_changed():
     _golden_loco("humanoid_alt", ops.humanoid_step, 108, True)
+
+
+def test_ant_golden_on_non_finite_state():
+    """NaN / +-Inf in the simulator tensors of some environments: every output as the reference leaves it
+    (NaN where it has NaN, flags exact), and no other environment touched."""
+    _golden_loco("ant_nonfinite", ops.ant_step, 60, False)
+
+
+def test_humanoid_golden_on_non_finite_state():
+    _golden_loco("humanoid_nonfinite", ops.humanoid_step, 108, True)
 
 
 def _vs_oracle(spec, step, ostep, n, with_rand, steps=2):

@@ -10,7 +10,7 @@ from tests import helpers as H
 import pytest
 
 
-@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample"])
+@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample", "cartpole_nonfinite"])
 def test_cartpole_oracle_matches_reference(name):
     g = H.load_golden(name)
     m = g["meta"]
@@ -97,3 +97,13 @@ def test_ant_oracle_matches_reference_with_every_parameter_changed():
 
 def test_humanoid_oracle_matches_reference_with_every_parameter_changed():
     _run_loco("humanoid_alt", oracle.humanoid_step, 108, True)
+
+
+def test_ant_oracle_matches_reference_on_non_finite_state():
+    """NaN / +-Inf in root rows, joint state, actions and sensors of some environments (a physics blow-up): flags,
+    rewards and every finite or NaN output as the reference's own arithmetic leaves them."""
+    _run_loco("ant_nonfinite", oracle.ant_step, 60, False)
+
+
+def test_humanoid_oracle_matches_reference_on_non_finite_state():
+    _run_loco("humanoid_nonfinite", oracle.humanoid_step, 108, True)

@@ -10,9 +10,10 @@ from tests import helpers as H
 from tests.math_cases import AFFINE, MULTI, ROWWISE, check_outputs
 
 
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
 @pytest.mark.parametrize("name,ins,outk,exact,scale", ROWWISE)
-def test_rowwise(name, ins, outk, exact, scale):
-    g = H.load_golden("math")
+def test_rowwise(name, ins, outk, exact, scale, fixture):
+    g = H.load_golden(fixture)
     got = oracle.rowwise(name, *[g[k] for k in ins])
     ref = g[outk]
     assert got.shape == ref.shape
@@ -24,9 +25,10 @@ def test_rowwise(name, ins, outk, exact, scale):
         H.assert_close(got, ref, scale=scale, what=name)
 
 
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
 @pytest.mark.parametrize("name", AFFINE)
-def test_affine(name):
-    g = H.load_golden("math")
+def test_affine(name, fixture):
+    g = H.load_golden(fixture)
     got = oracle.affine(name, g["aff_x"], g["aff_lo"], g["aff_hi"])
     assert H.bit_equal_fraction(got, g[name]) == 1.0
 
@@ -66,10 +68,11 @@ class OracleTJ:
     calc_heading_quat = staticmethod(lambda q: OracleTJ._one("calc_heading_quat", [q], 4))
 
 
+@pytest.mark.parametrize("fixture", ["math2", "math2_nonfinite"])
 @pytest.mark.parametrize("case", MULTI, ids=[c[0] for c in MULTI])
-def test_remaining_functions(case):
+def test_remaining_functions(case, fixture):
     cid, fn, args, outk, classes, scale = case
-    g = H.load_golden("math2")
+    g = H.load_golden(fixture)
     got = getattr(OracleTJ, fn)(*[g[a] if isinstance(a, str) else a for a in args])
     check_outputs(H, got, g, outk, classes, scale, cid)
 
