@@ -246,7 +246,7 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     8 x 2^20 Humanoid environments with an RCCL all-gather of episode statistics)."""
     from isaacgym_amd.episode_stats import EpisodeStats
 
-    def timed(fn, k=steps, warmup=5):
+    def timed(fn, k=steps, warmup=12):  # three passes over the rotating sets before the clock starts
         for i in range(warmup):
             fn(i)
         torch.cuda.synchronize()
