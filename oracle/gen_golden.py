@@ -1133,7 +1133,7 @@ def gen_hand_forces():
 
 def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, object_type="block",
                 max_consecutive_successes=0, use_relative_control=False, act_moving_average=None,
-                force_scale=None, force_prob_range=(0.001, 0.1)):
+                force_scale=None, force_prob_range=(0.001, 0.1), poison=False):
     """ShadowHand (tasks/shadow_hand.py): pre_physics_step (resets + targets of the 20 actuated joints)
     and post_physics_step (observation layouts :473-584, compute_hand_reward :747-800) of the reference
     class on synthetic simulator tensors."""
@@ -1257,6 +1257,9 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
             L = t.max_episode_length
             t.progress_buf[:4] = torch.tensor([L - 4, L - 3, L - 2, L - 1])
         actions = torch.rand(N, A, generator=g) * 2 - 1
+        if poison:  # a policy that blew up in a few environments
+            o = 30 + 12 * step
+            actions[o, 2], actions[o + 1, 0], actions[o + 1, 7] = float("nan"), float("inf"), -float("inf")
         rec["actions"].append(actions.numpy().copy())
         env_ids = t.reset_buf.nonzero(as_tuple=False).squeeze(-1)
         goal_ids = t.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
@@ -1316,6 +1319,19 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
         q[4:8] = t.goal_states[4:8, 3:7]
         obj[:, 3:7] = q
         obj[:, 7:13] = torch.randn(N, 6, generator=g)
+        if poison:  # a simulation that blew up in a few other environments
+            o = 30 + 12 * step
+            nan, inf = float("nan"), float("inf")
+            obj[o + 2, 0] = nan
+            obj[o + 3, 3:7] = nan
+            obj[o + 4, 1] = inf
+            obj[o + 5, 9] = -inf
+            t.dof_state.view(N, D, 2)[o + 6, 3, 0] = nan
+            t.dof_state.view(N, D, 2)[o + 7, 1, 1] = inf
+            t.dof_force_tensor[o + 8, 2] = nan
+            obj[o + 9, 3:7] = 0.0
+            t.vec_sensor_tensor[o + 10, 4] = nan
+            t.rigid_body_states[o + 11, :, 0:7] = nan     # every body of one environment (the fingertips among them)
         t.root_state_tensor[t.object_indices] = obj
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
         rec["in_dof_force"].append(t.dof_force_tensor.numpy().copy())
@@ -2173,6 +2189,7 @@ def gen_nonfinite_tasks():
     """Cartpole and AllegroHand on non-finite simulator state / actions (HumanoidAMP's comes out of gen_motion)."""
     gen_cartpole(seed=93, N=128, T=4, name="cartpole_nonfinite", poison=True)
     _gen_allegro("nonfinite", N=96, T=4, seed=94, poison=True)
+    _gen_shadow("nonfinite", N=70, T=3, seed=95, poison=True)
 
 
 GENERATORS = {"nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}

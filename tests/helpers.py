@@ -28,7 +28,8 @@ def close(x, ref, scale=1.0, rtol=RTOL):
     x = np.asarray(x)
     ref = np.asarray(ref)
     tol = rtol * np.maximum(np.abs(ref), scale)
-    ok = np.abs(x.astype(np.float64) - ref.astype(np.float64)) <= tol
+    with np.errstate(invalid="ignore"):  # inf - inf of equal infinities: caught by x == ref below
+        ok = np.abs(x.astype(np.float64) - ref.astype(np.float64)) <= tol
     ok |= np.isnan(x) & np.isnan(ref)
     ok |= (x == ref)
     return ok
@@ -264,7 +265,7 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros, force_fn=None):
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
 
-SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen", "force"]
+SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen", "force", "nonfinite"]
 
 
 def shadow_params(meta, g, seed=0, rng_offset=0):
