@@ -246,7 +246,9 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     8 x 2^20 Humanoid environments with an RCCL all-gather of episode statistics)."""
     from isaacgym_amd.episode_stats import EpisodeStats
 
-    def timed(fn, k=steps, warmup=12):  # three passes over the rotating sets before the clock starts
+    WARMUP = 12  # three passes over the rotating sets before the clock starts
+
+    def timed(fn, k=steps, warmup=WARMUP):
         for i in range(warmup):
             fn(i)
         torch.cuda.synchronize()
@@ -349,7 +351,7 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     report("amp_demo_fetch_device_sampling", timed(fetch, 4 * steps), nb * K, None,
            "fetch_amp_obs_demo with device-side draws: igx_motion_sample + igx_motion_amp_obs_steps, %d trajectories x %d "
            "history steps per fetch; no host transfer, no synchronisation" % (nb, K))
-    rec = TrajectoryRecorder(nb, K * 105, None, 4 * steps + 5, dev)
+    rec = TrajectoryRecorder(nb, K * 105, None, 4 * steps + WARMUP, dev)
 
     def fetch_and_stream(i):
         fetch(i)
