@@ -67,3 +67,33 @@ def test_get_euler_xyz_at_the_wrap_vs_oracle_large():
     ref = OracleTJ.get_euler_xyz(q)
     for name, a, b in zip(("roll", "pitch", "yaw"), got, ref):
         H.assert_angle_close(a.cpu().numpy().reshape(-1), np.asarray(b).reshape(-1), what=name)
+
+
+def test_ant_2_to_24_environments_strict_against_oracle():
+    """The whole 16.7 M-environment batch (4 GB of observations), every yaw / roll / angle_to_target entry
+    compared strictly with the CPU checker; a quarter of the torso rotations sit on the remainder wrap."""
+    n = 1 << 24
+    spec = synthetic.ANT
+    p = synthetic.loco_params(spec, seed=11, rng_offset=4)
+    t = synthetic.loco_state(spec, n, 29, DEV)
+    quarter = n // 4
+    t["root_states"][:quarter, 3:7] = _dev(H.edge_quats(quarter, 31))
+    ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+    ops.ant_step(p, t, n)
+    torch.cuda.synchronize()
+    oracle.ant_step(p, ref, n)
+    ang = list(H.LOCO_ANGLE_COLS)
+    got = t["obs"][:, 7:10].cpu().numpy()
+    want = ref["obs"][:, 7:10]
+    d = np.abs(got.astype(np.float64) - want)
+    print("entries:", d.size, "reference values within 3e-3 of 2 pi:", int((want[:, 0:2] > 6.28).sum()), "more than 1 rad apart:",
+          int((d > 1.0).sum()), "max residual: %.3g" % d.max())
+    H.assert_angle_close(got, want, what="2^24 environments")
+    for k in ("reset", "progress"):
+        assert np.array_equal(t[k].cpu().numpy(), ref[k]), k
+    for k in ("potentials", "rew"):
+        assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, k
+    nonangle = [c for c in range(60) if c not in ang]
+    for s0 in range(0, n, 1 << 22):  # the other 57 columns bit for bit, in slices (host memory)
+        a = t["obs"][s0:s0 + (1 << 22)].cpu().numpy()
+        assert H.bit_equal_fraction(a[:, nonangle], ref["obs"][s0:s0 + (1 << 22)][:, nonangle]) == 1.0, s0
