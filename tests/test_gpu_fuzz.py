@@ -11,6 +11,10 @@ from oracle import oracle  # noqa: E402
 from tests import helpers as H  # noqa: E402
 
 DEV = "cuda:0"
+# a longer campaign: IGX_FUZZ_TRIALS multiplies the number of trials of every test, IGX_FUZZ_SEED moves the seeds
+import os  # noqa: E402
+TRIALS = max(1, int(os.environ.get("IGX_FUZZ_TRIALS", "1")))
+SEED = int(os.environ.get("IGX_FUZZ_SEED", "0")) * 1000
 
 
 def _sizes(rng, tile, count):
@@ -25,10 +29,10 @@ def _sizes(rng, tile, count):
 def test_loco_fuzz(humanoid):
     spec = synthetic.HUMANOID if humanoid else synthetic.ANT
     step, ostep = (ops.humanoid_step, oracle.humanoid_step) if humanoid else (ops.ant_step, oracle.ant_step)
-    rng = np.random.default_rng(100 + humanoid)
+    rng = np.random.default_rng(100 + humanoid + SEED)
     nobs = spec["num_obs"]
     nonangle = [c for c in range(nobs) if c not in H.LOCO_ANGLE_COLS]
-    for trial, n in enumerate(_sizes(rng, 32 if humanoid else 64, 12)):
+    for trial, n in enumerate(_sizes(rng, 32 if humanoid else 64, 12 * TRIALS)):
         p = synthetic.loco_params(spec, seed=int(rng.integers(1 << 40)), rng_offset=int(rng.integers(1 << 20)))
         for name in ("dof_vel_scale", "contact_force_scale", "angular_velocity_scale", "up_weight", "heading_weight",
                      "actions_cost_scale", "energy_cost_scale", "joints_at_limit_cost_scale"):
@@ -68,8 +72,8 @@ def test_loco_fuzz(humanoid):
 
 
 def test_cartpole_fuzz():
-    rng = np.random.default_rng(7)
-    for trial, n in enumerate(_sizes(rng, 64, 12)):
+    rng = np.random.default_rng(7 + SEED)
+    for trial, n in enumerate(_sizes(rng, 64, 12 * TRIALS)):
         p = synthetic.cartpole_params(seed=int(rng.integers(1 << 40)), rng_offset=int(rng.integers(1 << 20)))
         p.reset_dist = float(rng.uniform(0.5, 4.0))
         p.max_episode_length_m1 = float(rng.integers(3, 600))
@@ -86,13 +90,13 @@ def test_cartpole_fuzz():
 
 @pytest.mark.parametrize("hand", ["allegro", "shadow"])
 def test_hand_fuzz(hand):
-    rng = np.random.default_rng(31 if hand == "allegro" else 32)
+    rng = np.random.default_rng((31 if hand == "allegro" else 32) + SEED)
     obs_types = ["full_no_vel", "full", "full_state"] + (["openai"] if hand == "shadow" else [])
     mk_p, mk_s = (synthetic.allegro_params, synthetic.allegro_state) if hand == "allegro" else (synthetic.shadow_params, synthetic.shadow_state)
     pre, post = (ops.allegro_pre_physics, ops.allegro_post_physics) if hand == "allegro" else (ops.shadow_pre_physics, ops.shadow_post_physics)
     opre, opost = ((oracle.allegro_pre_physics, oracle.allegro_post_physics) if hand == "allegro"
                    else (oracle.shadow_pre_physics, oracle.shadow_post_physics))
-    for trial, n in enumerate(_sizes(rng, 64, 10)):
+    for trial, n in enumerate(_sizes(rng, 64, 10 * TRIALS)):
         obs_type = str(rng.choice(obs_types))
         asym = bool(rng.integers(2))
         p = mk_p(obs_type, seed=int(rng.integers(1 << 40)), rng_offset=int(rng.integers(1 << 20)))
