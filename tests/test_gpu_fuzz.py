@@ -139,3 +139,73 @@ def test_hand_fuzz(hand):
             assert H.bit_equal_fraction(t["states"].cpu().numpy(), ref["states"]) == 1.0, what
         H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what=what)
         H.assert_close(t["consecutive_successes"].cpu().numpy(), ref["consecutive_successes"], what=what)
+
+
+def test_amp_fuzz():
+    """HumanoidAMP step: random batch sizes around the 32-row tile, 2 - 5 history steps (the three specialised
+    kernels and the general one), both root-observation frames, random thresholds, optional tail outputs."""
+    rng = np.random.default_rng(41 + SEED)
+    for trial, n in enumerate(_sizes(rng, 32, 10 * TRIALS)):
+        K = int(rng.choice([2, 2, 3, 4, 5]))
+        p = synthetic.amp_params(K, bool(rng.integers(2)), bool(rng.integers(2)), int(rng.integers(3, 400)))
+        p.termination_height = float(rng.uniform(0.2, 1.0))
+        t = synthetic.amp_state(n, int(rng.integers(1 << 30)), DEV, K, int(p.max_episode_length_m1) + 1)
+        if rng.integers(2):
+            p.clip_obs = float(rng.uniform(0.1, 3.0))
+            t["obs_clamped"] = torch.zeros(n, 105, device=DEV)
+            t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
+        ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+        what = "amp trial %d n %d K %d" % (trial, n, K)
+        ops.humanoid_amp_step(p, t, n)
+        torch.cuda.synchronize()
+        oracle.humanoid_amp_step(p, ref, n)
+        for k in ("reset", "terminate", "progress"):
+            assert np.array_equal(t[k].cpu().numpy(), ref[k]), (k, what)
+        assert np.array_equal(t["rew"].cpu().numpy(), ref["rew"]), what
+        H.assert_amp_obs_close(t["obs"].cpu().numpy(), ref["obs"], what=what, quiet=True)
+        got, want = t["amp_obs"].cpu().numpy(), ref["amp_obs"]
+        H.assert_amp_obs_close(got[:, 0], want[:, 0], what=what + " amp_obs", quiet=True)
+        assert np.array_equal(got[:, 1:].view(np.uint32), want[:, 1:].view(np.uint32)), what  # shifted history: copies
+        if "time_outs" in t:
+            assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), what
+            assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -p.clip_obs, p.clip_obs)), what
+
+
+def test_motion_fuzz():
+    """Motion library: random sample counts around the 16-sample block, times beyond both ends of the clips,
+    the state kernel and the fused observation kernels (one step and tiled over 1 - 4 history steps)."""
+    g = H.load_golden("motion")
+    tabs_np = H.motion_tabs_from_golden(g)
+    tabs_dev = {k: torch.from_numpy(v).to(DEV) for k, v in tabs_np.items()}
+    tables = ops.motion_tables(tabs_dev)
+    rng = np.random.default_rng(43 + SEED)
+    for trial, n in enumerate(_sizes(rng, 16, 10 * TRIALS)):
+        ids = rng.integers(0, 2, n).astype(np.int64)
+        # up to ~0.12 s before the clip's start (the reference reaches back numAMPObsSteps * dt, humanoid_amp.py:158-159,
+        # :283-284: the blend is then negative and slerp extrapolates) and 20 % beyond its end (clamped to the last frame).
+        # Far before the start the extrapolation multiplies the last-bit differences of acos / sin by |blend|: at
+        # -0.3 clip lengths (blend -27 ... -54) the root tan-norm columns of this kernel and the checker are 1.5e-5 apart.
+        times = rng.uniform(-0.04, 1.2, n) * tabs_np["motion_length"][ids]
+        K, dt, lro = int(rng.integers(1, 5)), float(rng.uniform(0.005, 0.08)), bool(rng.integers(2))
+        what = "motion trial %d n %d K %d" % (trial, n, K)
+        out = torch.zeros(n, K * 105, device=DEV)
+        ops.motion_amp_obs_steps(tables, torch.from_numpy(ids).to(DEV), torch.from_numpy(times).to(DEV), K, dt, lro, out)
+        want = oracle.motion_amp_obs_steps(tabs_np, ids, times, K, dt, lro)
+        got = out.cpu().numpy()
+        # frames are exact (fp64 index arithmetic), so the copied joint velocities are bit-equal; the rest goes
+        # through slerp / acos / sin: 1e-5 per group, except joints on the identity knife edge of quat_to_angle_axis
+        gv, wv = got.reshape(-1, 105)[:, 65:93], want.reshape(-1, 105)[:, 65:93]
+        assert np.array_equal(gv.view(np.uint32), wv.view(np.uint32)), what
+        # which joints sit on the knife edge (masked to zero on one side only): from the joint angles of the same samples
+        ids_t = np.tile(np.expand_dims(ids, -1), [1, K]).flatten()
+        times_t = (np.expand_dims(times, -1) + (-dt * np.arange(0, K))).flatten()
+        dp = torch.zeros(n * K, 28, device=DEV)
+        ops.motion_state(tables, torch.from_numpy(ids_t).to(DEV), torch.from_numpy(times_t).to(DEV), dict(dof_pos=dp))
+        disagree, _ = H.knife_edge_joints(dp.cpu().numpy(), oracle.motion_state(tabs_np, ids_t, times_t)["dof_pos"])
+        exempt = np.zeros((n * K, 105), bool)
+        for j, cols in enumerate(H.amp_joint_columns("obs")):
+            exempt[:, cols] |= disagree[:, j:j + 1]
+        H.assert_amp_obs_close(got.reshape(-1, 105), want.reshape(-1, 105), what=what, exempt=exempt, quiet=True)
+        jump = np.abs(got.reshape(-1, 105) - want.reshape(-1, 105))[exempt]
+        # (the recording's clips hold joints at exactly zero rotation; a few samples per thousand land on the edge)
+        assert disagree.sum() <= 2 + (n * K) // 250 and (jump.size == 0 or jump.max() < 2e-2), (what, int(disagree.sum()))
