@@ -323,6 +323,67 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
            "if the whole 780-B body rows are counted" % n)
     del sets, caches
 
+    # the torch_jit_utils functions the path names, one launch each on 2^22 rows into preallocated outputs (three
+    # rotating input sets: 2^22 rows of three sets do not stay in the 256 MB last-level cache)
+    from isaacgym_amd import _lib
+    m = 1 << 22
+    gen = torch.Generator(device=dev).manual_seed(9 + rank)
+
+    def unit_quats():
+        q = torch.randn(m, 4, device=dev, generator=gen)
+        return q / q.norm(dim=-1, keepdim=True)
+
+    Q = [(unit_quats(), unit_quats()) for _ in range(3)]
+    V = [torch.randn(m, 3, device=dev, generator=gen) for _ in range(3)]
+    T = [torch.rand(m, 1, device=dev, generator=gen) for _ in range(3)]
+    X = [torch.randn(m, 8, device=dev, generator=gen) for _ in range(3)]
+    lo8, hi8 = -torch.rand(8, device=dev, generator=gen) - 0.1, torch.rand(8, device=dev, generator=gen) + 0.1
+    o4, o3, o8 = torch.empty(m, 4, device=dev), torch.empty(m, 3, device=dev), torch.empty(m, 8, device=dev)
+    for name, nbytes, fn in (
+            ("quat_mul", 48, lambda i: _lib.call_rowwise("igx_quat_mul", list(Q[i % 3]), o4, m)),
+            ("quat_conjugate", 32, lambda i: _lib.call_rowwise("igx_quat_conjugate", [Q[i % 3][0]], o4, m)),
+            ("quat_rotate", 40, lambda i: _lib.call_rowwise("igx_quat_rotate", [Q[i % 3][0], V[i % 3]], o3, m)),
+            ("slerp", 52, lambda i: _lib.call_rowwise("igx_slerp", [Q[i % 3][0], Q[i % 3][1], T[i % 3]], o4, m)),
+            ("scale", 64, lambda i: _lib.call_affine("igx_scale", X[i % 3], lo8, hi8, o8, m, 8)),
+            ("unscale", 64, lambda i: _lib.call_affine("igx_unscale", X[i % 3], lo8, hi8, o8, m, 8)),
+            ("tensor_clamp", 64, lambda i: _lib.call_affine("igx_tensor_clamp", X[i % 3], lo8, hi8, o8, m, 8))):
+        report("torch_jit_utils." + name, timed(fn), m, nbytes, "torch_jit_utils.%s, %d rows per launch" % (name, m))
+    del Q, V, T, X, o4, o3, o8
+
+    # Cartpole (configuration 1's task on the GPU) and the tasks either side of the path's five: ShadowHand,
+    # HumanoidImitate (2^19 environments: their rows are twice as wide), AntImitate with its exact quantile
+    pc = synthetic.cartpole_params(1, 0)
+    sets = [synthetic.cartpole_state(n, 100 * rank + s, dev) for s in range(4)]
+    caches = [dict() for _ in sets]
+    report("cartpole_step", timed(lambda i: ops.cartpole_step(pc, sets[i % 4], n, caches[i % 4])), n, 68,
+           "Cartpole observations + compute_cartpole_reward + resets, %d envs" % n)
+    del sets, caches
+    half = max(n // 2, 1)
+    ps = synthetic.shadow_params("full_state", 1, 0)
+    sets = [synthetic.shadow_state(half, 400 * rank + s, dev) for s in range(3)]
+    caches = [dict() for _ in sets]
+    report("shadow_post", timed(lambda i: ops.shadow_post_physics(ps, sets[i % 3], half, caches[i % 3])), half, 1732,
+           "ShadowHand post_physics_step (full_state observations + compute_hand_reward + global sums), %d envs" % half)
+    del sets, caches
+    ph = synthetic.him_params(1, 0)
+    sets = [synthetic.him_state(half, 600 * rank + s, dev) for s in range(2)]
+    report("humanoid_imitate_step", timed(lambda i: ops.humanoid_imitate_step(ph, sets[i % 2], half)), half, 1928,
+           "HumanoidImitate post_physics_step (observations + imitation reward + resets), %d envs" % half)
+    del sets
+    from isaacgym_amd import _abi
+    pi = synthetic.loco_params(synthetic.ANT, 1, 0)
+    sets = [synthetic.loco_state(synthetic.ANT, n, 700 * rank + s, dev) for s in range(3)]
+    lo, hi = (torch.tensor(v, device=dev, dtype=torch.float64) for v in synthetic.loco_limits(8))
+    clip = lo + (hi - lo) * torch.rand(64, 8, device=dev, dtype=torch.float64)
+    frame = torch.randint(0, 60, (n,), device=dev)
+    pose_diff = torch.zeros(n, dtype=torch.float64, device=dev)
+    qws = torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=dev)
+    im = ops.imitate_args(clip, frame, pose_diff, qws, 0.99, 1.8, -2.0)
+    report("ant_imitate_step", timed(lambda i: ops.ant_imitate_step(pi, sets[i % 3], im, n)), n, 556 + 32,
+           "AntImitate post_physics_step: observations, exact 0.99 quantile of the pose differences over all %d envs "
+           "(torch.quantile), reward and resets" % n)
+    del sets
+
     # motion library: fetch_amp_obs_demo's kernel (configuration 5: 1 024 trajectories per fetch)
     tabs = synthetic_motion_tables(torch, dev)
     tables = ops.motion_tables(tabs)
