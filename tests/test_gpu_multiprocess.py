@@ -72,6 +72,25 @@ def test_bench_world_of_one_through_rccl_with_configs():
     assert d["rccl_ranks"] == 1 and d["config"]["collective_backend"] == "nccl" and d["collectives"]["barrier"] == "nccl"
     assert d["roofline"]["traffic"] is None  # the committed PMC figure belongs to the 2^20-env run only
     for name in ("humanoid_step", "allegro_post", "allegro_pre", "humanoid_amp_step", "motion_amp_obs_1024",
-                 "motion_amp_obs_1048576", "amp_demo_fetch_device_sampling", "amp_demo_fetch_streamed_to_host"):
+                 "motion_amp_obs_1048576", "amp_demo_fetch_device_sampling", "amp_demo_fetch_streamed_to_host",
+                 "torch_jit_utils.quat_mul", "torch_jit_utils.tensor_clamp", "cartpole_step", "shadow_post",
+                 "humanoid_imitate_step", "ant_imitate_step"):
         assert d["configs"][name]["us"] > 0, name
     assert d["configs"]["humanoid_step"]["bytes_per_unit"] == 940 and "frac" in d["configs"]["humanoid_amp_step"]
+
+
+def test_bench_two_ranks_with_configs_run_the_sharded_humanoid_configuration():
+    """Two ranks (on one device, so over the gloo fallback): the configurations ride along on every rank, the
+    slowest rank's time is reported, and the Humanoid shard runs the episode-statistics kernel per step with the
+    totals all-gathered over the ranks (the block that only a world larger than one executes)."""
+    rc, lines, err = _bench("--gpus", "2", "--all-ranks-on-device", "0", "--allow-gloo-fallback", "--config-steps", "3")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * 65536
+    c = d["configs"]["humanoid_step+episode_stats"]
+    assert c["us"] > 0 and c["bytes_per_unit"] == 940 + 28 and "2 ranks" in c["what"] and "over gloo" in c["what"]
+    assert d["collectives"]["episode_stats_all_gather"] == "gloo"
+    for name in ("humanoid_step", "allegro_post", "humanoid_amp_step", "torch_jit_utils.slerp", "cartpole_step",
+                 "shadow_post", "humanoid_imitate_step", "ant_imitate_step", "motion_amp_obs_1024"):
+        assert d["configs"][name]["us"] > 0, name
