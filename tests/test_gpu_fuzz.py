@@ -209,3 +209,78 @@ def test_motion_fuzz():
         jump = np.abs(got.reshape(-1, 105) - want.reshape(-1, 105))[exempt]
         # (the recording's clips hold joints at exactly zero rotation; a few samples per thousand land on the edge)
         assert disagree.sum() <= 2 + (n * K) // 250 and (jump.size == 0 or jump.max() < 2e-2), (what, int(disagree.sum()))
+
+
+def test_humanoid_imitate_fuzz():
+    """HumanoidImitate step: random batch sizes around the 16-row tile, random thresholds and weights, host-given or
+    in-kernel reset draws, optional tail outputs."""
+    rng = np.random.default_rng(47 + SEED)
+    for trial, n in enumerate(_sizes(rng, 16, 8 * TRIALS)):
+        p = synthetic.him_params(seed=int(rng.integers(1 << 30)), rng_offset=int(rng.integers(1000)),
+                                 termination_radius=float(rng.uniform(0.3, 2.0)))
+        p.termination_height = float(rng.uniform(0.4, 1.1))
+        p.up_weight = float(rng.uniform(0.0, 1.0))
+        p.actions_cost_scale = float(rng.uniform(0.0, 0.1))
+        p.dof_vel_scale = float(rng.uniform(0.05, 1.0))
+        p.max_episode_length_m1 = float(rng.integers(3, 1200))
+        t = synthetic.him_state(n, int(rng.integers(1 << 30)), DEV, bool(rng.integers(2)))
+        t["progress"] = torch.from_numpy(rng.integers(0, int(p.max_episode_length_m1) + 2, n)).to(DEV)
+        t["reset"] = torch.from_numpy((rng.random(n) < rng.choice([0.0, 0.05, 1.0])).astype(np.int64)).to(DEV)
+        if rng.integers(2):
+            p.clip_obs = float(rng.uniform(0.1, 3.0))
+            t["obs_clamped"] = torch.zeros(n, 205, device=DEV)
+            t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
+        ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+        what = "him trial %d n %d" % (trial, n)
+        ops.humanoid_imitate_step(p, t, n)
+        torch.cuda.synchronize()
+        oracle.humanoid_imitate_step(p, ref, n)
+        for k in ("reset", "progress", "randomize"):
+            assert np.array_equal(t[k].cpu().numpy(), ref[k]), (k, what)
+        for k in ("obs", "dof_state", "potentials", "prev_potentials"):
+            assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, (k, what)
+        H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what=what + " rew")
+        if "time_outs" in t:
+            assert np.array_equal(t["time_outs"].cpu().numpy(), ref["time_outs"]), what
+            assert torch.equal(t["obs_clamped"], torch.clamp(t["obs"], -p.clip_obs, p.clip_obs)), what
+
+
+def test_ant_imitate_fuzz():
+    """AntImitate step (observations, exact quantile over all environments, reward, resets): random batch sizes on
+    both sides of the one-workgroup select (<= 4096 values) and the multi-launch one, random quantile, distance
+    floor, clip length, thresholds; the quantile value and the pose differences are compared bit for bit."""
+    from isaacgym_amd import _abi
+    rng = np.random.default_rng(53 + SEED)
+    lo, hi = synthetic.loco_limits(8)
+    lo_t, hi_t = torch.tensor(lo, device=DEV, dtype=torch.float64), torch.tensor(hi, device=DEV, dtype=torch.float64)
+    sizes = _sizes(rng, 64, 6 * TRIALS) + [int(rng.integers(4000, 4200)) for _ in range(2 * TRIALS)] + \
+        [int(rng.integers(5000, 60000)) for _ in range(2 * TRIALS)]
+    for trial, n in enumerate(sizes):
+        F = int(rng.integers(4, 80))  # the clip is used up to its last three frames (ant_imitate.py:547)
+        p = synthetic.loco_params(synthetic.ANT, seed=int(rng.integers(1 << 30)), rng_offset=int(rng.integers(1000)))
+        p.termination_height = float(rng.uniform(0.1, 0.7))
+        p.max_episode_length_m1 = float(rng.integers(3, 1200))
+        t = synthetic.loco_state(synthetic.ANT, n, int(rng.integers(1 << 30)), DEV, with_rand=bool(rng.integers(2)))
+        gen = torch.Generator(device=DEV).manual_seed(int(rng.integers(1 << 30)))
+        arrays = dict(motion=lo_t + (hi_t - lo_t) * torch.rand(F, 8, generator=gen, device=DEV, dtype=torch.float64),
+                      target_pose_idx=torch.randint(0, F - 1, (n,), generator=gen, device=DEV),
+                      pose_diff=torch.zeros(n, dtype=torch.float64, device=DEV))
+        q, floor, death = float(rng.choice([0.0, 0.5, 0.9, 0.99, 1.0, rng.random()])), float(rng.uniform(0.0, 4.0)), -2.0
+        ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+        ref_arrays = {k: v.cpu().numpy().copy() for k, v in arrays.items()}
+        ws = torch.zeros(_abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+        what = "ant imitate trial %d n %d F %d q %r" % (trial, n, F, q)
+        for step in range(2):
+            p.rng_offset += 1
+            im = ops.imitate_args(arrays["motion"], arrays["target_pose_idx"], arrays["pose_diff"], ws, q, floor, death)
+            ops.ant_imitate_step(p, t, im, n)
+            torch.cuda.synchronize()
+            qv = oracle.ant_imitate_step(p, ref, oracle.imitate_args(ref_arrays, F, q, floor, death, n), ref_arrays, n)
+            assert float(ws.view(torch.float64)[5]) == qv, what
+            assert np.array_equal(arrays["pose_diff"].cpu().numpy().view(np.uint64), ref_arrays["pose_diff"].view(np.uint64)), what
+            assert np.array_equal(arrays["target_pose_idx"].cpu().numpy(), ref_arrays["target_pose_idx"]), what
+            for k in ("reset", "progress", "randomize"):
+                assert np.array_equal(t[k].cpu().numpy(), ref[k]), (k, what)
+            H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what=what + " rew")
+            for k in ("dof_state", "potentials", "prev_potentials"):
+                assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, (k, what)
