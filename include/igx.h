@@ -1022,6 +1022,11 @@ int igx_exp_map_to_angle_axis(const float *exp_map, float *angle, float *axis, i
 /* :630-641 calc_heading(q) -> [n]; :643-654 calc_heading_quat(q) -> [n,4] */
 int igx_calc_heading(const float *q, float *out, int64_t n, igx_stream_t stream);
 int igx_calc_heading_quat(const float *q, float *out, int64_t n, igx_stream_t stream);
+/* :670-681 extract_positions_from_rigid_body_states(tensor [n, >= 13 * num_bodies]) -> [n, 3 * num_bodies]: columns
+ * 13 i + {0, 1, 2} of every row, i < num_bodies (the reference fixes num_bodies = 22, HumanoidImitate's body count:
+ * tasks/humanoid_imitate.py:708, :811).  row_stride = floats between consecutive rows of `states`. */
+int igx_extract_positions_from_rigid_body_states(const float *states, int64_t row_stride, int32_t num_bodies, float *out,
+                                                 int64_t n, igx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,7 @@ for _name, _narr in (("igx_quat_unit", 2), ("igx_quat_apply", 3), ("igx_tf_inver
 SYMBOLS["igx_normalize"] = (C.c_int, [_P, _P, _I64, C.c_int32, _P])
 SYMBOLS["igx_copysign"] = (C.c_int, [C.c_float, _P, _P, _I64, _P])
 SYMBOLS["igx_quat_axis"] = (C.c_int, [_P, C.c_int32, _P, _I64, _P])
+SYMBOLS["igx_extract_positions_from_rigid_body_states"] = (C.c_int, [_P, _I64, C.c_int32, _P, _I64, _P])
 SYMBOLS["igx_torch_rand_float"] = (C.c_int, [C.c_double, C.c_double, _P, C.c_uint64, C.c_uint64, _P, _I64, _P])
 SYMBOLS["igx_compute_heading_and_up"] = (C.c_int, [_P] * 5 + [C.c_int32] + [_P] * 5 + [_I64, _P])
 

@@ -603,9 +603,67 @@ static int run_affine(const char *who, const float *x, const float *lower, const
     return launch_status(who);
 }
 
+// :670-681 extract_positions_from_rigid_body_states: columns 13 i + {0, 1, 2}, i < bodies, of every row
+// (the position of each body out of its 13-float state).  Every 64-byte line of a row holds part of a
+// position, so the whole row is delivered either way: a block streams EXT_ROWS whole rows through LDS
+// with 16-byte loads and writes the picked columns as one contiguous run.
+constexpr int EXT_ROWS = 16;
+constexpr int EXT_MAX_BODIES = 32;
+
+__global__ __launch_bounds__(256) void extract_positions_tile_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                                     int64_t n, int bodies)
+{
+    __shared__ __align__(16) float s_rows[EXT_ROWS * EXT_MAX_BODIES * 13];
+    const int w = bodies * 13, ow = bodies * 3;
+    const int64_t r0 = (int64_t)blockIdx.x * EXT_ROWS;
+    const int rows = (n - r0 >= EXT_ROWS) ? EXT_ROWS : (int)(n - r0);
+    const int chunks = rows * w / 4;  // rows * w is a multiple of 4 for a full tile; the last tile's tail is scalar
+    const v4f *src = reinterpret_cast<const v4f *>(x + r0 * w);
+    for (int k = threadIdx.x; k < chunks; k += 256) *reinterpret_cast<v4f *>(s_rows + 4 * k) = ld_stream(src + k);
+    for (int k = 4 * chunks + threadIdx.x; k < rows * w; k += 256) s_rows[k] = x[r0 * w + k];
+    __syncthreads();
+    float *dst = out + r0 * ow;
+    for (int k = threadIdx.x; k < rows * ow; k += 256) {
+        const int r = k / ow, c = k - r * ow, body = c / 3;
+        dst[k] = s_rows[r * w + body * 13 + (c - body * 3)];
+    }
+}
+
+__global__ __launch_bounds__(256) void extract_positions_kernel(const float *__restrict__ x, int64_t row_stride,
+                                                                float *__restrict__ out, int64_t total, int bodies)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= total) return;
+    const int ow = bodies * 3;
+    const int64_t r = k / ow;
+    const int c = (int)(k - r * ow), body = c / 3;
+    out[k] = x[r * row_stride + body * 13 + (c - body * 3)];
+}
+
 }  // namespace igx
 
 using namespace igx;
+
+extern "C" int igx_extract_positions_from_rigid_body_states(const float *states, int64_t row_stride, int32_t num_bodies,
+                                                            float *out, int64_t n, igx_stream_t s)
+{
+    const char *who = "igx_extract_positions_from_rigid_body_states";
+    if (num_bodies < 1 || num_bodies > EXT_MAX_BODIES) return fail(IGX_E_PARAM, "%s: num_bodies %d outside [1, %d]", who, num_bodies, EXT_MAX_BODIES);
+    if (row_stride < (int64_t)num_bodies * 13) return fail(IGX_E_SIZE, "%s: rows of %lld floats do not hold %d bodies", who, (long long)row_stride, num_bodies);
+    if (n < 0 || n > ((int64_t)1 << 36)) return fail(IGX_E_SIZE, "%s: n out of range", who);
+    if (n == 0) return IGX_OK;
+    if (!states || !out) return fail(IGX_E_NULL, "%s: NULL argument", who);
+    hipStream_t st = static_cast<hipStream_t>(s);
+    if (row_stride == (int64_t)num_bodies * 13 && aligned16(states) && (EXT_ROWS * num_bodies * 13) % 4 == 0) {
+        hipLaunchKernelGGL(extract_positions_tile_kernel, dim3((unsigned)((n + EXT_ROWS - 1) / EXT_ROWS)), dim3(256), 0, st,
+                           states, out, n, (int)num_bodies);
+    } else {
+        const int64_t total = n * num_bodies * 3;
+        hipLaunchKernelGGL(extract_positions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, states,
+                           row_stride, out, total, (int)num_bodies);
+    }
+    return launch_status(who);
+}
 
 extern "C" int igx_quat_mul(const float *a, const float *b, float *out, int64_t n, igx_stream_t s)
 {

@@ -261,6 +261,19 @@ def calc_heading_quat(q):  # :643-654
     return _run_multi("igx_calc_heading_quat", (q,), (4,), (4,), (q.shape,))[0]
 
 
+def extract_positions_from_rigid_body_states(tensor, num_bodies: int = 22):  # :670-681 (22 bodies there)
+    """[n, >= 13 * num_bodies] flattened rigid-body states -> [n, 3 * num_bodies] positions."""
+    if tensor.dim() != 2 or tensor.shape[1] < 13 * num_bodies:
+        raise IndexError("expected [n, >= %d], got %s" % (13 * num_bodies, tuple(tensor.shape)))
+    x = tensor.contiguous().float()
+    n = x.shape[0]
+    out = torch.empty((n, 3 * num_bodies), dtype=torch.float32, device=x.device)
+    fn = _lib.lib().igx_extract_positions_from_rigid_body_states
+    _lib.check(_lib._launch(fn, x.device, _lib.tensor_ptr(x), C.c_int64(x.shape[1]), C.c_int32(num_bodies),
+                            _lib.tensor_ptr(out), C.c_int64(n)))
+    return out
+
+
 def unscale_np(x, lower, upper):  # :244-245 (numpy on the host, as in the reference)
     return (2.0 * x - upper - lower) / (upper - lower)
 

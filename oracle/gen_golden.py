@@ -2192,10 +2192,40 @@ def gen_nonfinite_tasks():
     _gen_shadow("nonfinite", N=70, T=3, seed=95, poison=True)
 
 
-GENERATORS = {"nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+def gen_extract_positions(seed=77):
+    """extract_positions_from_rigid_body_states (utils/torch_jit_utils.py:670-681) on [n, 286] and wider rows.
+    Run with PYTORCH_JIT=0, like humanoid_imitate: the function builds its index tensor on "cuda:0", and un-scripted
+    that one allocation can be redirected to the CPU while the rest runs as written."""
+    assert os.environ.get("PYTORCH_JIT") == "0", "run as: PYTORCH_JIT=0 python oracle/gen_golden.py extract_positions"
+    _install_gym_stubs()
+    tj = ref_shim.load("isaacgymenvs.utils.torch_jit_utils")
+    real_empty = torch.empty
+
+    def cpu_empty(*a, **k):
+        if str(k.get("device", "")) == "cuda:0":
+            k["device"] = "cpu"
+        return real_empty(*a, **k)
+
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    torch.empty = cpu_empty
+    try:
+        for name, n, w in (("a", 67, 286), ("b", 1, 286), ("c", 33, 300)):
+            x = torch.randn(n, w, generator=g)
+            x[0, 0], x[-1, -1] = float("nan"), float("inf")
+            out["in_" + name] = x.numpy().copy()
+            out["out_" + name] = tj.extract_positions_from_rigid_body_states(x).numpy().copy()
+    finally:
+        torch.empty = real_empty
+    out["meta"] = np.array(_meta(note="reference function run with PYTORCH_JIT=0, its cuda:0 index tensor redirected to the CPU"))
+    np.savez_compressed(os.path.join(OUT, "extract_positions.npz"), **out)
+    print("extract_positions.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+GENERATORS = {"extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    names = sys.argv[1:] or [n for n in GENERATORS if n != "humanoid_imitate"]  # that one needs PYTORCH_JIT=0
+    names = sys.argv[1:] or [n for n in GENERATORS if n not in ("humanoid_imitate", "extract_positions")]  # those need PYTORCH_JIT=0
     for n in names:
         GENERATORS[n]()

@@ -857,6 +857,14 @@ int orc_quat_axis(const float *q, int32_t axis, float *o, int64_t n)
     for (int64_t i = 0; i < n; ++i) { float t[3]; quat_rotate_s(q + 4 * i, basis, t, 0); memcpy(o + 3 * i, t, 12); }
     return 0;
 }
+/* :670-681 extract_positions_from_rigid_body_states: columns 13 i + {0, 1, 2}, i < num_bodies, of every row */
+int orc_extract_positions(const float *x, int64_t row_stride, int32_t num_bodies, float *o, int64_t n)
+{
+    for (int64_t r = 0; r < n; ++r)
+        for (int i = 0; i < num_bodies; ++i)
+            for (int j = 0; j < 3; ++j) o[r * 3 * num_bodies + 3 * i + j] = x[r * row_stride + 13 * i + j];
+    return 0;
+}
 /* :292-310 */
 int orc_scale_transform(const float *x, const float *lo, const float *hi, float *o, int64_t n, int32_t d)
 {

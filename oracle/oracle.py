@@ -271,6 +271,15 @@ def normalize(x):
     return out
 
 
+def extract_positions(x, num_bodies=22):
+    """utils/torch_jit_utils.py:670-681 on a [n, >= 13 * num_bodies] array."""
+    x = _f32(x)
+    out = np.empty((x.shape[0], 3 * num_bodies), np.float32)
+    assert lib().orc_extract_positions(C.c_void_p(x.ctypes.data), C.c_int64(x.shape[1]), C.c_int32(num_bodies),
+                                       C.c_void_p(out.ctypes.data), C.c_int64(x.shape[0])) == 0
+    return out
+
+
 def torch_rand_float(lower, upper, uniforms, seed=0, rng_offset=0, count=None):
     u = None if uniforms is None else _f32(uniforms)
     count = u.size if u is not None else count

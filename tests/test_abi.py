@@ -120,6 +120,10 @@ def test_every_entry_point_rejects_null_structs():
     assert lib.igx_compute_rot(*([None] * 11), 4, None) == _abi.IGX_E_NULL
     assert lib.igx_compute_heading_and_up(*([None] * 5), 3, *([None] * 5), 4, None) == _abi.IGX_E_PARAM
     assert lib.igx_quat_axis(None, 5, None, 4, None) == _abi.IGX_E_PARAM
+    assert lib.igx_extract_positions_from_rigid_body_states(None, 286, 33, None, 4, None) == _abi.IGX_E_PARAM
+    assert lib.igx_extract_positions_from_rigid_body_states(None, 285, 22, None, 4, None) == _abi.IGX_E_SIZE
+    assert lib.igx_extract_positions_from_rigid_body_states(None, 286, 22, None, 4, None) == _abi.IGX_E_NULL
+    assert lib.igx_extract_positions_from_rigid_body_states(None, 286, 22, None, 0, None) == 0
     assert lib.igx_normalize(None, None, 4, 5, None) == _abi.IGX_E_PARAM
     assert lib.igx_torch_rand_float(0.0, 1.0, None, 0, 0, None, 4, None) == _abi.IGX_E_NULL
     assert lib.igx_get_euler_xyz(None, None, None, None, 0, None) == 0

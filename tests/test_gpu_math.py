@@ -158,3 +158,24 @@ def test_torch_rand_float():
     assert float(got.min()) >= -1.0 and float(got.max()) < 3.0 and abs(float(got.mean()) - 1.0) < 0.1
     other = tj.torch_rand_float(-1.0, 3.0, (1001, 7), DEV, seed=77, rng_offset=6)
     assert not torch.equal(got, other)
+
+
+def test_extract_positions_golden_and_sizes():
+    """extract_positions_from_rigid_body_states (utils/torch_jit_utils.py:670-681): the reference's recording (rows of
+    286 and of 300 floats), then batch sizes around the 16-row tile, other body counts, unaligned bases and wide rows
+    against the CPU checker; pure column selection, bit for bit."""
+    g = H.load_golden("extract_positions")
+    for name in "abc":
+        got = tj.extract_positions_from_rigid_body_states(_dev(g["in_" + name])).cpu().numpy()
+        assert got.shape == g["out_" + name].shape and H.bit_equal_fraction(got, g["out_" + name]) == 1.0, name
+    rng = np.random.default_rng(5)
+    for n, width, bodies, offset in ((0, 286, 22, 0), (1, 286, 22, 0), (15, 286, 22, 0), (16, 286, 22, 0), (17, 286, 22, 0),
+                                     (1000, 286, 22, 0), (100003, 286, 22, 0), (333, 195, 15, 0), (333, 300, 22, 0),
+                                     (50, 13, 1, 0), (257, 416, 32, 0), (100, 286, 22, 1)):
+        flat = rng.standard_normal(n * width + offset).astype(np.float32)
+        x = _dev(flat)[offset:].view(n, width)  # offset 1: a base that is not 16-byte aligned
+        got = tj.extract_positions_from_rigid_body_states(x, bodies).cpu().numpy()
+        want = oracle.extract_positions(flat[offset:].reshape(n, width), bodies)
+        assert got.shape == (n, 3 * bodies) and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, width, bodies)
+    with pytest.raises(IndexError):
+        tj.extract_positions_from_rigid_body_states(torch.zeros(4, 285, device=DEV))

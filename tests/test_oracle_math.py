@@ -81,3 +81,15 @@ def test_torch_rand_float_from_recorded_draws():
     g = H.load_golden("math2")
     got = oracle.torch_rand_float(-0.2, 0.35, g["rand_u"])
     assert H.bit_equal_fraction(got, g["torch_rand_float"]) == 1.0
+
+
+def test_extract_positions_on_the_reference_recording():
+    """utils/torch_jit_utils.py:670-681, recorded from the reference's function (rows of 286 and 300 floats, a NaN and
+    an Inf among the inputs): pure column selection, bit for bit."""
+    g = H.load_golden("extract_positions")
+    for name in "abc":
+        got = oracle.extract_positions(g["in_" + name])
+        assert got.shape == g["out_" + name].shape and H.bit_equal_fraction(got, g["out_" + name]) == 1.0, name
+    x = g["in_c"]
+    assert np.array_equal(oracle.extract_positions(x, 15).view(np.uint32),
+                          x.reshape(33, 300)[:, :195].reshape(33, 15, 13)[:, :, :3].reshape(33, 45).view(np.uint32))
