@@ -277,8 +277,17 @@ def _launch(fn, dev, *args):
         return fn(*args, current_stream(dev))
 
 
-def _data_ptr(t):
-    return 0 if t is None else t.data_ptr()
+_TENSOR_DATA_PTR = torch.Tensor.data_ptr  # the unbound slot: map() calls it without a Python frame per tensor
+
+
+def _held(tensors):
+    """The tensors among `tensors` (absent optional buffers are None), as a cache entry keeps them."""
+    return [t for t in tensors if t is not None]
+
+
+def _pointers(held):
+    """Where each tensor of a cache entry points now (the per-call re-validation of the cached structs)."""
+    return list(map(_TENSOR_DATA_PTR, held))
 
 
 def _storages(tensors):
@@ -298,7 +307,7 @@ def call_step(symbol, params, bufcls, tensors, n, cache=None):
         ent = cache.get(symbol)
         # same tensor objects, same n, and every one of them still points where it did when the struct was
         # validated (`t.data = ...`, set_() and resize_() keep a tensor's identity but move its memory)
-        if ent is not None and ent[0] == ids and ent[1] == n and list(map(_data_ptr, ent[6])) == ent[7]:
+        if ent is not None and ent[0] == ids and ent[1] == n and _pointers(ent[6]) == ent[7]:
             check(_launch(ent[2], ent[4], C.byref(params), ent[3], C.c_int64(n)))
             return
     check_sizes(bufcls, params, tensors, n, symbol)
@@ -307,8 +316,8 @@ def call_step(symbol, params, bufcls, tensors, n, cache=None):
         raise ValueError("no device buffers given")
     fn = getattr(lib(), symbol)
     if cache is not None:  # the entry keeps the tensors alive, so their ids cannot be reused while it exists
-        held = list(tensors.values())
-        cache[symbol] = (ids, n, fn, C.byref(b), dev, b, held, list(map(_data_ptr, held)), _storages(held))
+        held = _held(tensors.values())
+        cache[symbol] = (ids, n, fn, C.byref(b), dev, b, held, _pointers(held), _storages(held))
     check(_launch(fn, dev, C.byref(params), C.byref(b), C.c_int64(n)))
 
 

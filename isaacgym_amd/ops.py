@@ -359,7 +359,7 @@ def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0
     if cache is not None and noise is None:
         key = (id(actions), id(targets), id(actions_out), id(gain), id(offset), mode, power_scale, clip_actions, num_dof)
         ent = cache.get("igx_action_stage_step")
-        if ent is not None and ent[0] == key and list(map(_lib._data_ptr, ent[4])) == ent[5]:
+        if ent is not None and ent[0] == key and _lib._pointers(ent[4]) == ent[5]:
             _lib.check(_lib._launch(_lib.lib().igx_action_stage_step, dev, ent[1], ent[2]))
             return
     modes = {"force": _abi.IGX_ACT_FORCE, "pd_target": _abi.IGX_ACT_PD_TARGET, "first_dof": _abi.IGX_ACT_FIRST_DOF}
@@ -387,9 +387,8 @@ def action_stage(actions, targets, mode, gain=None, offset=None, power_scale=1.0
     if noise is not None:
         s.noise = noise.struct(actions.numel(), fresh)
     if key is not None:
-        held = (actions, targets, actions_out, gain, offset)
-        cache["igx_action_stage_step"] = (key, C.byref(s), C.c_int64(n), s, held, list(map(_lib._data_ptr, held)),
-                                          _lib._storages(held))
+        held = _lib._held((actions, targets, actions_out, gain, offset))
+        cache["igx_action_stage_step"] = (key, C.byref(s), C.c_int64(n), s, held, _lib._pointers(held), _lib._storages(held))
     _lib.check(_lib._launch(_lib.lib().igx_action_stage_step, dev, C.byref(s), C.c_int64(n)))
 
 
@@ -406,7 +405,7 @@ def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_ep
         key = (id(obs_buf), id(obs_out), id(progress), id(reset), id(time_outs), id(states_buf), id(states_out),
                clip_obs, max_episode_length)
         ent = cache.get("igx_vec_task_tail_step")
-        if ent is not None and ent[0] == key and list(map(_lib._data_ptr, ent[4])) == ent[5]:
+        if ent is not None and ent[0] == key and _lib._pointers(ent[4]) == ent[5]:
             _lib.check(_lib._launch(_lib.lib().igx_vec_task_tail_step, dev, ent[1], ent[2]))
             return
     t = _abi.VecTaskTail()
@@ -432,9 +431,8 @@ def vec_task_tail(obs_buf, obs_out, clip_obs, progress, reset, time_outs, max_ep
     t.max_episode_length_m1 = float(max_episode_length - 1)
     t.clip_obs = float(clip_obs)
     if key is not None:
-        held = (obs_buf, obs_out, progress, reset, time_outs, states_buf, states_out)
-        cache["igx_vec_task_tail_step"] = (key, C.byref(t), C.c_int64(n), t, held, list(map(_lib._data_ptr, held)),
-                                           _lib._storages(held))
+        held = _lib._held((obs_buf, obs_out, progress, reset, time_outs, states_buf, states_out))
+        cache["igx_vec_task_tail_step"] = (key, C.byref(t), C.c_int64(n), t, held, _lib._pointers(held), _lib._storages(held))
     _lib.check(_lib._launch(_lib.lib().igx_vec_task_tail_step, dev, C.byref(t), C.c_int64(n)))
 
 
@@ -469,15 +467,15 @@ def _imitate_call(symbol, params, tensors, im, n_envs, cache=None):
     if cache is not None:
         ids = tuple(map(id, tensors.values()))
         ent = cache.get(symbol)
-        if ent is not None and ent[0] == ids and ent[1] == n_envs and list(map(_lib._data_ptr, ent[6])) == ent[7]:
+        if ent is not None and ent[0] == ids and ent[1] == n_envs and _lib._pointers(ent[6]) == ent[7]:
             _lib.check(_lib._launch(ent[2], ent[4], C.byref(params), ent[3], C.byref(im), C.c_int64(n_envs)))
             return
     _lib.check_sizes(_abi.LocoBuffers, params, tensors, n_envs, symbol)
     b, dev = _lib.make_buffers(_abi.LocoBuffers, tensors)
     fn = getattr(_lib.lib(), symbol)
     if cache is not None:
-        held = list(tensors.values())
-        cache[symbol] = (ids, n_envs, fn, C.byref(b), dev, b, held, list(map(_lib._data_ptr, held)), _lib._storages(held))
+        held = _lib._held(tensors.values())
+        cache[symbol] = (ids, n_envs, fn, C.byref(b), dev, b, held, _lib._pointers(held), _lib._storages(held))
     _lib.check(_lib._launch(fn, dev, C.byref(params), C.byref(b), C.byref(im), C.c_int64(n_envs)))
 
 
