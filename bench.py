@@ -246,7 +246,8 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     8 x 2^20 Humanoid environments with an RCCL all-gather of episode statistics)."""
     from isaacgym_amd.episode_stats import EpisodeStats
 
-    WARMUP = 12  # three passes over the rotating sets before the clock starts
+    WARMUP = 40  # ten passes over the rotating sets before the clock starts (the first ~100 launches on freshly
+                 # allocated buffers run 2 % slower than the ones after them: tools/humanoid_spread.py)
 
     def timed(fn, k=steps, warmup=WARMUP):
         for i in range(warmup):
