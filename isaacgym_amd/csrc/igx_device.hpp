@@ -92,16 +92,17 @@ __device__ __forceinline__ f3 quat_rotate(f4 q, f3 v)
 #define IGX_TWO_PI_F 6.2831855f
 
 // torch.remainder(atan2(y, x), float32(2*pi)).  |atan2| <= pi, so fmod leaves the value alone and what is
-// left of remainder is its sign fix-up: add 2*pi to a negative non-zero value.  Whether atan2(y, x) is
-// negative is decided on the NUMERATOR, which is plain IEEE arithmetic and therefore bit-identical to the
-// reference's: the result is negative exactly when y < 0 (y = -0 gives -0, which remainder leaves alone, or
-// -pi behind a negative / negative-zero x).  Deciding on the library's atan2 result instead would let a
-// tiny negative quotient that it rounds or flushes to -0 lose its 2*pi: an observation error of 6.28.
+// left of remainder is its sign fix-up: add 2*pi to a negative NON-ZERO value.  A non-zero result carries the
+// sign of y (-pi behind y = -0 and a negative x included), so its own sign decides.  A zero result is left
+// alone by the reference when its atan2 gave +-0 as well: y = +-0, or a negative y whose quotient y / x
+// underflows to zero (y = -1e-40 against x = 1e30, or x = +Inf).  The one case in which a zero result must
+// still become 2*pi is a library that rounds or flushes a tiny negative quotient to -0 where the reference's
+// keeps the subnormal: that is decided on the quotient itself, one IEEE division, the same everywhere.
 // NaN stays NaN.
 __device__ __forceinline__ float atan2_mod_2pi(float y, float x)
 {
     const float a = atan2f(y, x);
-    const bool negative = (y < 0.0f) || (y == 0.0f && __builtin_signbit(y) && __builtin_signbit(x));
+    const bool negative = (a < 0.0f) || (a == 0.0f && y < 0.0f && y / x != 0.0f);
     return negative ? a + IGX_TWO_PI_F : a;
 }
 

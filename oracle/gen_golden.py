@@ -350,6 +350,18 @@ def _poison_loco(t, step, humanoid):
         t.dof_force_tensor[o + 15, 0] = inf
 
 
+def _scatter_extremes(g, tensors, frac=0.02):
+    """Huge, tiny, subnormal, signed-zero and non-finite values over about `frac` of the entries of every given
+    tensor (in place): what the reference's arithmetic makes of them is the contract, as for NaN / Inf."""
+    specials = torch.tensor([float("nan"), float("inf"), -float("inf"), 3e38, -3e38, 1e30, -1e30, 1e-30, 1e-40, -1e-45,
+                             0.0, -0.0, 1e19, -1e19, 1e-20], dtype=torch.float)
+    for x in tensors:
+        flat = x.view(-1)
+        m = max(1, int(flat.numel() * frac))
+        idx = torch.randint(0, flat.numel(), (m,), generator=g)
+        flat[idx] = specials[torch.randint(0, len(specials), (m,), generator=g)]
+
+
 def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_over=None, dt=None, targets=None,
               start_rotation=None, poison=False):
     """env_over / dt / targets / start_rotation: non-default values, so that a recording also pins how every
@@ -407,7 +419,10 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_o
     torch.manual_seed(seed + 100)
     for step in range(T):
         _loco_inputs(t, N, D, S, g, z_mean, z_std, humanoid)
-        if poison:
+        if poison == "extreme":
+            _scatter_extremes(g, [t.root_states, t.dof_state, t.vec_sensor_tensor, t.actions] +
+                              ([t.dof_force_tensor] if humanoid else []))
+        elif poison:
             _poison_loco(t, step, humanoid)
         rec["in_root"].append(t.root_states.numpy().copy())
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
@@ -665,6 +680,13 @@ def gen_loco_nonfinite():
     """Ant and Humanoid with NaN / +-Inf in the simulator tensors of some environments."""
     _gen_loco("ant_nonfinite", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, 91, 96, 4, poison=True)
     _gen_loco("humanoid_nonfinite", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, 92, 96, 4, poison=True)
+
+
+def gen_loco_extreme():
+    """Ant and Humanoid with huge / tiny / subnormal / signed-zero / non-finite values scattered over 2 % of the
+    simulator state and the actions."""
+    _gen_loco("ant_extreme", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, 93, 192, 3, poison="extreme")
+    _gen_loco("humanoid_extreme", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, 94, 192, 3, poison="extreme")
 
 
 # --------------------------------------------------------------------------
@@ -2222,7 +2244,7 @@ def gen_extract_positions(seed=77):
     print("extract_positions.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+GENERATORS = {"loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -358,3 +358,11 @@ def test_cached_call_follows_a_repointed_tensor():
     t["root_states"].data = torch.zeros(n // 2, 13, device=DEV)   # new memory, too short for n environments
     with pytest.raises(ValueError, match="root_states"):
         ops.ant_step(p, t, n, cache)
+
+
+@pytest.mark.parametrize("name,nobs,humanoid", [("ant_extreme", 60, False), ("humanoid_extreme", 108, True)])
+def test_loco_golden_on_extreme_values(name, nobs, humanoid):
+    """The reference's recording with +-3e38, +-1e30, 1e-30, subnormals, signed zeros, NaN and +-Inf scattered over
+    2 % of the simulator state and the actions: overflow, underflow, subnormal arithmetic and the sign of zero on
+    the GPU as in torch on the CPU."""
+    _golden_loco(name, ops.humanoid_step if humanoid else ops.ant_step, nobs, humanoid)

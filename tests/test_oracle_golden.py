@@ -107,3 +107,11 @@ def test_ant_oracle_matches_reference_on_non_finite_state():
 
 def test_humanoid_oracle_matches_reference_on_non_finite_state():
     _run_loco("humanoid_nonfinite", oracle.humanoid_step, 108, True)
+
+
+@pytest.mark.parametrize("name,step,nobs,humanoid", [("ant_extreme", "ant_step", 60, False),
+                                                     ("humanoid_extreme", "humanoid_step", 108, True)])
+def test_loco_oracle_matches_reference_on_extreme_values(name, step, nobs, humanoid):
+    """+-3e38, +-1e30, 1e-30, subnormals, signed zeros, NaN and +-Inf scattered over 2 % of the simulator state and
+    the actions: overflow to Inf, underflow, subnormal arithmetic and the sign of zero as the reference has them."""
+    _run_loco(name, getattr(oracle, step), nobs, humanoid)
