@@ -142,7 +142,9 @@ def gen_cartpole(seed=0, N=4096, T=4, name="cartpole", poison=False):
         ds[:, :, 1] = torch.randn(N, 2, generator=g)
         ds[0, 0, 0] = 3.0       # exactly resetDist: not > 3.0
         ds[1, 1, 0] = math.pi / 2  # float32(pi/2): not > float32(pi/2)
-        if poison:  # non-finite joint state in a few environments, other ones every step
+        if poison == "extreme":
+            _scatter_extremes(g, [ds], 0.05)
+        elif poison:  # non-finite joint state in a few environments, other ones every step
             o = 16 + 8 * step
             for i, (j, c, v) in enumerate([(0, 0, "nan"), (1, 0, "nan"), (0, 1, "nan"), (1, 1, "nan"), (0, 0, "inf"),
                                            (1, 0, "-inf"), (0, 1, "inf"), (1, 1, "-inf")]):
@@ -1026,7 +1028,9 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
         if step == 1:
             t.progress_buf[:4] = torch.tensor([596, 597, 598, 599])
         actions = torch.rand(N, D, generator=g) * 2 - 1
-        if poison:  # a policy that blew up in a few environments
+        if poison == "extreme":
+            _scatter_extremes(g, [actions], 0.01)
+        elif poison:  # a policy that blew up in a few environments
             o = 40 + 10 * step
             actions[o, 2], actions[o + 1, 0], actions[o + 1, 5] = float("nan"), float("inf"), -float("inf")
         rec["actions"].append(actions.numpy().copy())
@@ -1086,7 +1090,9 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
         q[4:8] = t.goal_states[4:8, 3:7]
         obj[:, 3:7] = q
         obj[:, 7:13] = torch.randn(N, 6, generator=g)
-        if poison:  # a simulation that blew up in a few other environments
+        if poison == "extreme":
+            _scatter_extremes(g, [obj, t.dof_state, t.dof_force_tensor], 0.01)
+        elif poison:  # a simulation that blew up in a few other environments
             o = 40 + 10 * step
             nan, inf = float("nan"), float("inf")
             obj[o + 2, 0] = nan              # object position
@@ -1279,7 +1285,9 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
             L = t.max_episode_length
             t.progress_buf[:4] = torch.tensor([L - 4, L - 3, L - 2, L - 1])
         actions = torch.rand(N, A, generator=g) * 2 - 1
-        if poison:  # a policy that blew up in a few environments
+        if poison == "extreme":
+            _scatter_extremes(g, [actions], 0.01)
+        elif poison:  # a policy that blew up in a few environments
             o = 30 + 12 * step
             actions[o, 2], actions[o + 1, 0], actions[o + 1, 7] = float("nan"), float("inf"), -float("inf")
         rec["actions"].append(actions.numpy().copy())
@@ -1341,7 +1349,9 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
         q[4:8] = t.goal_states[4:8, 3:7]
         obj[:, 3:7] = q
         obj[:, 7:13] = torch.randn(N, 6, generator=g)
-        if poison:  # a simulation that blew up in a few other environments
+        if poison == "extreme":
+            _scatter_extremes(g, [obj, t.dof_state, t.dof_force_tensor], 0.01)
+        elif poison:  # a simulation that blew up in a few other environments
             o = 30 + 12 * step
             nan, inf = float("nan"), float("inf")
             obj[o + 2, 0] = nan
@@ -1508,6 +1518,7 @@ def gen_motion(seed=11):
     _gen_amp_task(lib, hamp, seed + 7, N=64, K=3, name="amp_alt",
                   over=dict(localRootObs=True, terminationHeight=0.62, episodeLength=150))
     _gen_amp_task(lib, hamp, seed + 9, N=64, K=2, name="amp_nonfinite", poison=True)
+    _gen_amp_task(lib, hamp, seed + 11, N=96, K=2, T=3, name="amp_extreme", over=dict(localRootObs=True), poison="extreme")  # N=96: the file stays below 1 MB
 
 
 def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None, poison=False):
@@ -1589,7 +1600,9 @@ def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None, poison
         cf[4] = -3.0                                            # negative components never count
         cf[5, 3, 1] = 0.1                                       # exactly 0.1: not > 0.1
         t._contact_forces.copy_(cf)
-        if poison:  # non-finite simulator state in a few environments
+        if poison == "extreme":
+            _scatter_extremes(g, [t._root_states, t._dof_state, t._rigid_body_state, t._contact_forces], 0.004)
+        elif poison:  # non-finite simulator state in a few environments
             nan, inf = float("nan"), float("inf")
             t._root_states[40, 0], t._root_states[41, 6], t._root_states[42, 2] = nan, nan, inf
             t._root_states[43, 8], t._root_states[44, 3:7] = -inf, 0.0
@@ -2214,6 +2227,24 @@ def gen_nonfinite_tasks():
     _gen_shadow("nonfinite", N=70, T=3, seed=95, poison=True)
 
 
+def gen_extreme_tasks():
+    """Cartpole, AllegroHand, ShadowHand and every torch_jit_utils function on huge / tiny / subnormal / signed-zero /
+    non-finite values scattered over the simulator state, the actions and the functions' inputs (Ant / Humanoid:
+    gen_loco_extreme; HumanoidAMP's comes out of gen_motion)."""
+    gen_cartpole(seed=96, N=256, T=3, name="cartpole_extreme", poison="extreme")
+    _gen_allegro("extreme", N=128, T=3, seed=97, poison="extreme")
+    _gen_shadow("extreme", N=96, T=3, seed=98, poison="extreme")
+    gx = torch.Generator().manual_seed(99)
+
+    def scatter(x):
+        if x.is_floating_point() and x.numel() > 8:
+            _scatter_extremes(gx, [x], 0.03)
+        return x
+
+    gen_math(seed=15, n=384, name="math_extreme", P=scatter)
+    gen_math2(seed=16, n=384, name="math2_extreme", P=scatter)
+
+
 def gen_extract_positions(seed=77):
     """extract_positions_from_rigid_body_states (utils/torch_jit_utils.py:670-681) on [n, 286] and wider rows.
     Run with PYTORCH_JIT=0, like humanoid_imitate: the function builds its index tensor on "cuda:0", and un-scripted
@@ -2244,7 +2275,7 @@ def gen_extract_positions(seed=77):
     print("extract_positions.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+GENERATORS = {"extreme_tasks": gen_extreme_tasks, "loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

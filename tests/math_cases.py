@@ -68,6 +68,18 @@ MULTI = [
 ]
 
 
+def well_conditioned_rows(name, g):
+    """Rows of a ROWWISE case whose result is a function of the inputs rather than of the last bit of a library
+    function.  slerp evaluates sin(t * acos(c)): with |t| beyond a few units an ulp of acos (on which the math
+    libraries legitimately differ) is a large change of the argument - at t = 1e30 the sine is arbitrary, in the
+    reference as much as anywhere.  Rows with a finite |t| > 16 are left out (only the extreme-value recording has
+    any); non-finite t stays in (sin(Inf) is NaN everywhere)."""
+    if name != "slerp":
+        return slice(None)
+    t = np.abs(g["slerp_t"].reshape(-1))
+    return ~(np.isfinite(t) & (t > 16.0))
+
+
 def check_outputs(H, got, g, outk, classes, scale, what):
     """Compare the tuple `got` with the golden arrays named by outk."""
     if not isinstance(got, tuple):

@@ -7,7 +7,7 @@ import torch
 from isaacgym_amd.utils import torch_jit_utils as tj
 from oracle import oracle
 from tests import helpers as H
-from tests.math_cases import AFFINE, MULTI, ROWWISE, check_outputs
+from tests.math_cases import AFFINE, MULTI, ROWWISE, check_outputs, well_conditioned_rows
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -26,7 +26,7 @@ def _call(name, args):
     return fn(*args)
 
 
-@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite", "math_extreme"])
 @pytest.mark.parametrize("name,ins,outk,exact,scale", ROWWISE)
 def test_rowwise_golden(name, ins, outk, exact, scale, fixture):
     g = H.load_golden(fixture)
@@ -38,10 +38,11 @@ def test_rowwise_golden(name, ins, outk, exact, scale, fixture):
     elif name == "normalize_angle":
         H.assert_angle_close(got, ref, what=name, branch_cut="pi")  # atan2(sin, cos): +-pi are one answer
     else:
-        H.assert_close(got, ref, scale=scale, what=name)
+        rows = well_conditioned_rows(name, g)
+        H.assert_close(got[rows], ref[rows], scale=scale, what=name)
 
 
-@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite", "math_extreme"])
 @pytest.mark.parametrize("name", AFFINE)
 def test_affine_golden(name, fixture):
     g = H.load_golden(fixture)
@@ -99,7 +100,7 @@ def test_shapes_follow_the_reference():
     assert tj.quat_to_tan_norm(q[:, 0]).shape == (5, 6)
 
 
-@pytest.mark.parametrize("fixture", ["math2", "math2_nonfinite"])
+@pytest.mark.parametrize("fixture", ["math2", "math2_nonfinite", "math2_extreme"])
 @pytest.mark.parametrize("case", MULTI, ids=[c[0] for c in MULTI])
 def test_remaining_functions_golden(case, fixture):
     cid, fn, args, outk, classes, scale = case

@@ -16,7 +16,7 @@ def _to_dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample", "cartpole_nonfinite"])
+@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample", "cartpole_nonfinite", "cartpole_extreme"])
 def test_cartpole_golden(name):
     g = H.load_golden(name)
     m = g["meta"]

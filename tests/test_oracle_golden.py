@@ -10,7 +10,7 @@ from tests import helpers as H
 import pytest
 
 
-@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample", "cartpole_nonfinite"])
+@pytest.mark.parametrize("name", ["cartpole", "cartpole_sample", "cartpole_nonfinite", "cartpole_extreme"])
 def test_cartpole_oracle_matches_reference(name):
     g = H.load_golden(name)
     m = g["meta"]

@@ -7,10 +7,10 @@ import pytest
 
 from oracle import oracle
 from tests import helpers as H
-from tests.math_cases import AFFINE, MULTI, ROWWISE, check_outputs
+from tests.math_cases import AFFINE, MULTI, ROWWISE, check_outputs, well_conditioned_rows
 
 
-@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite", "math_extreme"])
 @pytest.mark.parametrize("name,ins,outk,exact,scale", ROWWISE)
 def test_rowwise(name, ins, outk, exact, scale, fixture):
     g = H.load_golden(fixture)
@@ -22,10 +22,11 @@ def test_rowwise(name, ins, outk, exact, scale, fixture):
     elif name == "normalize_angle":
         H.assert_angle_close(got, ref, what=name, branch_cut="pi")  # atan2(sin, cos): +-pi are one answer
     else:
-        H.assert_close(got, ref, scale=scale, what=name)
+        rows = well_conditioned_rows(name, g)
+        H.assert_close(got[rows], ref[rows], scale=scale, what=name)
 
 
-@pytest.mark.parametrize("fixture", ["math", "math_nonfinite"])
+@pytest.mark.parametrize("fixture", ["math", "math_nonfinite", "math_extreme"])
 @pytest.mark.parametrize("name", AFFINE)
 def test_affine(name, fixture):
     g = H.load_golden(fixture)
@@ -68,7 +69,7 @@ class OracleTJ:
     calc_heading_quat = staticmethod(lambda q: OracleTJ._one("calc_heading_quat", [q], 4))
 
 
-@pytest.mark.parametrize("fixture", ["math2", "math2_nonfinite"])
+@pytest.mark.parametrize("fixture", ["math2", "math2_nonfinite", "math2_extreme"])
 @pytest.mark.parametrize("case", MULTI, ids=[c[0] for c in MULTI])
 def test_remaining_functions(case, fixture):
     cid, fn, args, outk, classes, scale = case
