@@ -471,7 +471,7 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_o
     print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-def gen_ant_imitate(seed=41, N=257, T=7, F=9):
+def gen_ant_imitate(seed=41, N=257, T=7, F=9, name="ant_imitate", poison=False):
     """AntImitate (tasks/ant_imitate.py): Ant observations + the pose-imitation reward with its
     global quantile reset threshold (:447-555) and the target_pose_idx bookkeeping (:405-419)."""
     import contextlib
@@ -513,6 +513,8 @@ def gen_ant_imitate(seed=41, N=257, T=7, F=9):
             tgt = t.motion_to_imitate[(t.target_pose_idx + 1).clamp(max=F - 1)].float()
             t.dof_state.view(N, D, 2)[..., 0] = tgt + 0.02 * torch.randn(N, D, generator=g)
             t.reset_buf.zero_()  # no re-drawn joints in these steps
+        if poison == "extreme":
+            _scatter_extremes(g, [t.root_states, t.dof_state, t.vec_sensor_tensor, t.actions], 0.01)
         rec["in_reset"].append(t.reset_buf.numpy().copy())
         rec["in_root"].append(t.root_states.numpy().copy())
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
@@ -554,13 +556,13 @@ def gen_ant_imitate(seed=41, N=257, T=7, F=9):
                         joints_at_limit_cost_scale=e["jointsAtLimitCost"], termination_height=e["terminationHeight"],
                         death_cost=e["deathCost"], max_episode_length=e["episodeLength"], quantile=0.99,
                         distance_floor=1.8)
-    np.savez_compressed(os.path.join(OUT, "ant_imitate.npz"), **out)
-    print("ant_imitate.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
           "thresholds", out["threshold"], "resets", out["reset"].sum(1), "idx max", out["target_pose_idx"].max(1),
           "success", [(out["rew"][i] == 6.0).sum() for i in range(T)])
 
 
-def gen_humanoid_imitate(seed=51, N=67, T=4, F=48):
+def gen_humanoid_imitate(seed=51, N=67, T=4, F=48, name="humanoid_imitate", poison=False):
     """HumanoidImitate (tasks/humanoid_imitate.py): 63-dof humanoid, 205-wide observation (:795-831), pose /
     rigid-body tracking reward against frame 41 of the motion file (:672-758).
     Run with PYTORCH_JIT=0: extract_positions_from_rigid_body_states (utils/torch_jit_utils.py:670-681) builds its
@@ -618,6 +620,8 @@ def gen_humanoid_imitate(seed=51, N=67, T=4, F=48):
         if step == 2:  # joints near the target frame: large pose reward
             t.dof_state.view(N, D, 2)[..., 0] = t.motion_to_imitate[41, :D].float() + 0.01 * torch.randn(N, D, generator=g)
         t.rigid_body_states.copy_(torch.randn(N, NBODY * 13, generator=g) * 0.5)
+        if poison == "extreme":
+            _scatter_extremes(g, [t.root_states, t.dof_state, t.rigid_body_states, t.actions], 0.004)
         rec["in_root"].append(t.root_states.numpy().copy())
         rec["in_dof_state"].append(t.dof_state.numpy().copy())
         rec["in_rigid_body_states"].append(t.rigid_body_states.numpy().copy())
@@ -650,8 +654,8 @@ def gen_humanoid_imitate(seed=51, N=67, T=4, F=48):
                         dof_vel_scale=e["dofVelocityScale"], up_weight=e["upWeight"], actions_cost_scale=e["actionsCost"],
                         termination_height=e["terminationHeight"], termination_radius=e["terminationRadius"],
                         max_episode_length=e["episodeLength"], max_motor_effort=t.max_motor_effort, pose_frame=41)
-    np.savez_compressed(os.path.join(OUT, "humanoid_imitate.npz"), **out)
-    print("humanoid_imitate.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")},
           "resets", out["reset"].sum(1), "rew", out["rew"].mean(1))
 
 
@@ -2227,6 +2231,12 @@ def gen_nonfinite_tasks():
     _gen_shadow("nonfinite", N=70, T=3, seed=95, poison=True)
 
 
+def gen_imitate_extreme():
+    """AntImitate and HumanoidImitate on extreme values (run with PYTORCH_JIT=0, as humanoid_imitate needs)."""
+    gen_ant_imitate(seed=43, N=192, T=4, F=9, name="ant_imitate_extreme", poison="extreme")
+    gen_humanoid_imitate(seed=53, N=80, T=3, F=48, name="humanoid_imitate_extreme", poison="extreme")
+
+
 def gen_extreme_tasks():
     """Cartpole, AllegroHand, ShadowHand and every torch_jit_utils function on huge / tiny / subnormal / signed-zero /
     non-finite values scattered over the simulator state, the actions and the functions' inputs (Ant / Humanoid:
@@ -2275,10 +2285,10 @@ def gen_extract_positions(seed=77):
     print("extract_positions.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"extreme_tasks": gen_extreme_tasks, "loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+GENERATORS = {"imitate_extreme": gen_imitate_extreme, "extreme_tasks": gen_extreme_tasks, "loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    names = sys.argv[1:] or [n for n in GENERATORS if n not in ("humanoid_imitate", "extract_positions")]  # those need PYTORCH_JIT=0
+    names = sys.argv[1:] or [n for n in GENERATORS if n not in ("humanoid_imitate", "extract_positions", "imitate_extreme")]  # those need PYTORCH_JIT=0
     for n in names:
         GENERATORS[n]()

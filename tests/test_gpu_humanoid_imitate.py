@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_humanoid_imitate_golden():
-    H.him_replay(H.load_golden("humanoid_imitate"), ops.humanoid_imitate_step,
+@pytest.mark.parametrize("recording", ["humanoid_imitate", "humanoid_imitate_extreme"])
+def test_humanoid_imitate_golden(recording):
+    H.him_replay(H.load_golden(recording), ops.humanoid_imitate_step,
                  to_buf=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV), to_np=lambda t: t.cpu().numpy(),
                  zeros=lambda shape, dt: torch.zeros(shape, device=DEV,
                                                      dtype=torch.int64 if dt == np.int64 else torch.float32))

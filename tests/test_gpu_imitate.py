@@ -110,8 +110,9 @@ def test_quantile_passes_match_the_cpu_restatement():
     assert float(ws.view(torch.float64)[5]) == oracle.quantile_finish(ows) == float(torch.quantile(x.cpu(), 0.99))
 
 
-def test_ant_imitate_golden():
-    g = H.load_golden("ant_imitate")
+@pytest.mark.parametrize("recording", ["ant_imitate", "ant_imitate_extreme"])
+def test_ant_imitate_golden(recording):
+    g = H.load_golden(recording)
     ws = _ws()
 
     def step(p, bufs, arrays, m):

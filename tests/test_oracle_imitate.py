@@ -1,14 +1,16 @@
 """AntImitate: CPU checker against the recording of the reference task class
 (tests/golden/ant_imitate.npz), and the quantile restatement against torch.quantile."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import oracle
 from tests import helpers as H
 
 
-def test_ant_imitate_oracle_matches_reference():
-    g = H.load_golden("ant_imitate")
+@pytest.mark.parametrize("recording", ["ant_imitate", "ant_imitate_extreme"])  # extreme: huge / tiny / subnormal / non-finite inputs
+def test_ant_imitate_oracle_matches_reference(recording):
+    g = H.load_golden(recording)
 
     def step(p, bufs, arrays, m):
         im = oracle.imitate_args(arrays, m["F"], m["quantile"], m["distance_floor"], m["death_cost"], m["N"])
