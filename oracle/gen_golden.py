@@ -364,6 +364,12 @@ def _scatter_extremes(g, tensors, frac=0.02):
         flat[idx] = specials[torch.randint(0, len(specials), (m,), generator=g)]
 
 
+def _scale_quats(g, q):
+    """Quaternions that are not of unit length (in place): a simulator's drift, or a caller that never normalised;
+    the factor of each is drawn from 0.5 ... 2."""
+    q *= torch.rand(q.shape[0], 1, generator=g) * 1.5 + 0.5
+
+
 def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_over=None, dt=None, targets=None,
               start_rotation=None, poison=False):
     """env_over / dt / targets / start_rotation: non-default values, so that a recording also pins how every
@@ -424,6 +430,8 @@ def _gen_loco(name, modname, clsname, cfgname, D, S, humanoid, seed, N, T, env_o
         if poison == "extreme":
             _scatter_extremes(g, [t.root_states, t.dof_state, t.vec_sensor_tensor, t.actions] +
                               ([t.dof_force_tensor] if humanoid else []))
+        elif poison == "nonunit":
+            _scale_quats(g, t.root_states[:, 3:7])
         elif poison:
             _poison_loco(t, step, humanoid)
         rec["in_root"].append(t.root_states.numpy().copy())
@@ -1034,7 +1042,7 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
         actions = torch.rand(N, D, generator=g) * 2 - 1
         if poison == "extreme":
             _scatter_extremes(g, [actions], 0.01)
-        elif poison:  # a policy that blew up in a few environments
+        elif poison and poison != "nonunit":  # a policy that blew up in a few environments
             o = 40 + 10 * step
             actions[o, 2], actions[o + 1, 0], actions[o + 1, 5] = float("nan"), float("inf"), -float("inf")
         rec["actions"].append(actions.numpy().copy())
@@ -1096,6 +1104,8 @@ def _gen_allegro(name, N, T, seed, obs_type="full_state", asymmetric=False, obje
         obj[:, 7:13] = torch.randn(N, 6, generator=g)
         if poison == "extreme":
             _scatter_extremes(g, [obj, t.dof_state, t.dof_force_tensor], 0.01)
+        elif poison == "nonunit":
+            _scale_quats(g, obj[:, 3:7])  # (the goal rotations are the task's own products: unit length)
         elif poison:  # a simulation that blew up in a few other environments
             o = 40 + 10 * step
             nan, inf = float("nan"), float("inf")
@@ -1291,7 +1301,7 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
         actions = torch.rand(N, A, generator=g) * 2 - 1
         if poison == "extreme":
             _scatter_extremes(g, [actions], 0.01)
-        elif poison:  # a policy that blew up in a few environments
+        elif poison and poison != "nonunit":  # a policy that blew up in a few environments
             o = 30 + 12 * step
             actions[o, 2], actions[o + 1, 0], actions[o + 1, 7] = float("nan"), float("inf"), -float("inf")
         rec["actions"].append(actions.numpy().copy())
@@ -1355,6 +1365,8 @@ def _gen_shadow(name, N, T, seed, obs_type="full_state", asymmetric=False, objec
         obj[:, 7:13] = torch.randn(N, 6, generator=g)
         if poison == "extreme":
             _scatter_extremes(g, [obj, t.dof_state, t.dof_force_tensor], 0.01)
+        elif poison == "nonunit":
+            _scale_quats(g, obj[:, 3:7])  # (the goal rotations are the task's own products: unit length)
         elif poison:  # a simulation that blew up in a few other environments
             o = 30 + 12 * step
             nan, inf = float("nan"), float("inf")
@@ -1522,6 +1534,7 @@ def gen_motion(seed=11):
     _gen_amp_task(lib, hamp, seed + 7, N=64, K=3, name="amp_alt",
                   over=dict(localRootObs=True, terminationHeight=0.62, episodeLength=150))
     _gen_amp_task(lib, hamp, seed + 9, N=64, K=2, name="amp_nonfinite", poison=True)
+    _gen_amp_task(lib, hamp, seed + 13, N=64, K=2, T=3, name="amp_nonunit", over=dict(localRootObs=True), poison="nonunit")
     _gen_amp_task(lib, hamp, seed + 11, N=96, K=2, T=3, name="amp_extreme", over=dict(localRootObs=True), poison="extreme")  # N=96: the file stays below 1 MB
 
 
@@ -1606,6 +1619,8 @@ def _gen_amp_task(lib, hamp, seed, N=96, K=2, T=4, name="amp", over=None, poison
         t._contact_forces.copy_(cf)
         if poison == "extreme":
             _scatter_extremes(g, [t._root_states, t._dof_state, t._rigid_body_state, t._contact_forces], 0.004)
+        elif poison == "nonunit":
+            _scale_quats(g, t._root_states[:, 3:7])
         elif poison:  # non-finite simulator state in a few environments
             nan, inf = float("nan"), float("inf")
             t._root_states[40, 0], t._root_states[41, 6], t._root_states[42, 2] = nan, nan, inf
@@ -2231,6 +2246,15 @@ def gen_nonfinite_tasks():
     _gen_shadow("nonfinite", N=70, T=3, seed=95, poison=True)
 
 
+def gen_nonunit():
+    """Ant, Humanoid, AllegroHand and ShadowHand with root / object quaternions of length 0.5 ... 2
+    (HumanoidAMP's comes out of gen_motion)."""
+    _gen_loco("ant_nonunit", "isaacgymenvs.tasks.ant", "Ant", "Ant", 8, 24, False, 101, 160, 3, poison="nonunit")
+    _gen_loco("humanoid_nonunit", "isaacgymenvs.tasks.humanoid", "Humanoid", "Humanoid", 21, 12, True, 102, 128, 3, poison="nonunit")
+    _gen_allegro("nonunit", N=96, T=3, seed=103, poison="nonunit")
+    _gen_shadow("nonunit", N=70, T=3, seed=104, poison="nonunit")
+
+
 def gen_imitate_extreme():
     """AntImitate and HumanoidImitate on extreme values (run with PYTORCH_JIT=0, as humanoid_imitate needs)."""
     gen_ant_imitate(seed=43, N=192, T=4, F=9, name="ant_imitate_extreme", poison="extreme")
@@ -2285,7 +2309,7 @@ def gen_extract_positions(seed=77):
     print("extract_positions.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
-GENERATORS = {"imitate_extreme": gen_imitate_extreme, "extreme_tasks": gen_extreme_tasks, "loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
+GENERATORS = {"nonunit": gen_nonunit, "imitate_extreme": gen_imitate_extreme, "extreme_tasks": gen_extreme_tasks, "loco_extreme": gen_loco_extreme, "extract_positions": gen_extract_positions, "nonfinite_tasks": gen_nonfinite_tasks, "math_nonfinite": gen_math_nonfinite, "loco_nonfinite": gen_loco_nonfinite, "amp_demo": gen_amp_demo, "angles_edge": gen_angles_edge, "observer": gen_observer, "hand_forces": gen_hand_forces, "vectask": gen_vectask, "loco_alt": gen_loco_alt, "shadow": gen_shadow, "prestep": gen_prestep, "humanoid_imitate": gen_humanoid_imitate, "ant_imitate": gen_ant_imitate, "episode_stats": gen_episode_stats, "cartpole_sample": gen_cartpole_sample, "motion": gen_motion, "allegro": gen_allegro, "cartpole": gen_cartpole, "ant": gen_ant, "humanoid": gen_humanoid, "math": gen_math, "math2": gen_math2}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -123,7 +123,8 @@ def loco_branch_cut(humanoid):
 
 ALLEGRO_VARIANTS = ["default", "full", "no_vel_asym", "pen_maxsucc", "relative", "ema", "force",
                     "nonfinite",  # NaN / +-Inf actions and simulator state in a few environments
-                    "extreme"]    # huge, tiny, subnormal, signed-zero and non-finite values scattered over 1 % of them
+                    "extreme",    # huge, tiny, subnormal, signed-zero and non-finite values scattered over 1 % of them
+                    "nonunit"]    # object quaternions of length 0.5 ... 2
 
 
 def allegro_params(meta, g, seed=0, rng_offset=0):
@@ -266,7 +267,7 @@ def allegro_replay(g, pre_fn, post_fn, to_buf, to_np, zeros, force_fn=None):
         assert_close(to_np(b["consecutive_successes"]), g["consecutive_successes"][t], what=what + "cons")
 
 
-SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen", "force", "nonfinite", "extreme"]
+SHADOW_VARIANTS = ["default", "openai_asym", "full", "no_vel_pen", "force", "nonfinite", "extreme", "nonunit"]
 
 
 def shadow_params(meta, g, seed=0, rng_offset=0):

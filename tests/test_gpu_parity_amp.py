@@ -170,7 +170,7 @@ def test_motion_state_vs_oracle(motion, n):
     H.assert_amp_obs_close(host(fused), ref, what="fused amp obs n=%d" % n, exempt=exempt)
 
 
-@pytest.mark.parametrize("recording", ["amp", "amp_alt", "amp_nonfinite", "amp_extreme"])
+@pytest.mark.parametrize("recording", ["amp", "amp_alt", "amp_nonfinite", "amp_extreme", "amp_nonunit"])
 def test_amp_task_golden(motion, recording):
     _, _, _, tables = motion
     g = H.load_golden(recording)

@@ -360,7 +360,8 @@ def test_cached_call_follows_a_repointed_tensor():
         ops.ant_step(p, t, n, cache)
 
 
-@pytest.mark.parametrize("name,nobs,humanoid", [("ant_extreme", 60, False), ("humanoid_extreme", 108, True)])
+@pytest.mark.parametrize("name,nobs,humanoid", [("ant_extreme", 60, False), ("humanoid_extreme", 108, True),
+                                                ("ant_nonunit", 60, False), ("humanoid_nonunit", 108, True)])
 def test_loco_golden_on_extreme_values(name, nobs, humanoid):
     """The reference's recording with +-3e38, +-1e30, 1e-30, subnormals, signed zeros, NaN and +-Inf scattered over
     2 % of the simulator state and the actions: overflow, underflow, subnormal arithmetic and the sign of zero on

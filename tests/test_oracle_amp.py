@@ -7,7 +7,7 @@ from oracle import oracle
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("recording", ["amp", "amp_alt", "amp_nonfinite", "amp_extreme"])  # amp_alt: heading-frame root observation, 3 history steps,
+@pytest.mark.parametrize("recording", ["amp", "amp_alt", "amp_nonfinite", "amp_extreme", "amp_nonunit"])  # amp_alt: heading-frame root observation, 3 history steps,
 def test_amp_task_oracle_matches_reference(recording):     # other termination height and episode length
     g = H.load_golden(recording)
     tabs = H.motion_tabs_from_golden(H.load_golden("motion"))

@@ -110,7 +110,9 @@ def test_humanoid_oracle_matches_reference_on_non_finite_state():
 
 
 @pytest.mark.parametrize("name,step,nobs,humanoid", [("ant_extreme", "ant_step", 60, False),
-                                                     ("humanoid_extreme", "humanoid_step", 108, True)])
+                                                     ("humanoid_extreme", "humanoid_step", 108, True),
+                                                     ("ant_nonunit", "ant_step", 60, False),  # root quaternions of
+                                                     ("humanoid_nonunit", "humanoid_step", 108, True)])  # length 0.5 ... 2
 def test_loco_oracle_matches_reference_on_extreme_values(name, step, nobs, humanoid):
     """+-3e38, +-1e30, 1e-30, subnormals, signed zeros, NaN and +-Inf scattered over 2 % of the simulator state and
     the actions: overflow to Inf, underflow, subnormal arithmetic and the sign of zero as the reference has them."""
