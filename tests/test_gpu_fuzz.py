@@ -176,6 +176,11 @@ def test_amp_fuzz():
         K = int(rng.choice([2, 2, 3, 4, 5]))
         p = synthetic.amp_params(K, bool(rng.integers(2)), bool(rng.integers(2)), int(rng.integers(3, 400)))
         p.termination_height = float(rng.uniform(0.2, 1.0))
+        if rng.integers(2):  # other contact-exempt bodies (0 - 4 of them) and other key bodies than the hands and feet
+            nc = int(rng.integers(0, 5))
+            p.num_contact_bodies = nc
+            p.set("contact_body_ids", ([int(v) for v in rng.choice(15, nc, replace=False)] + [0, 0, 0, 0])[:4])
+            p.set("key_body_ids", [int(v) for v in rng.integers(0, 15, 4)])
         t = synthetic.amp_state(n, int(rng.integers(1 << 30)), DEV, K, int(p.max_episode_length_m1) + 1)
         if rng.integers(2):
             p.clip_obs = float(rng.uniform(0.1, 3.0))
