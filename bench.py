@@ -408,11 +408,11 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     batch = torch.empty(nb, K * 105, device=dev)
 
     def fetch(i):
-        ops.motion_sample(tables, cdf, d_ids, d_times, seed=5 + rank, rng_offset=i)
-        ops.motion_amp_obs_steps(tables, d_ids, d_times, K, 0.0332, False, batch)
+        ops.motion_fetch_amp_obs(tables, cdf, nb, K, 0.0332, False, batch, d_ids, d_times, seed=5 + rank, rng_offset=i)
     report("amp_demo_fetch_device_sampling", timed(fetch, 4 * steps), nb * K, None,
-           "fetch_amp_obs_demo with device-side draws: igx_motion_sample + igx_motion_amp_obs_steps, %d trajectories x %d "
-           "history steps per fetch; no host transfer, no synchronisation" % (nb, K))
+           "fetch_amp_obs_demo with device-side draws in one launch (igx_motion_fetch_amp_obs: the draws of "
+           "igx_motion_sample and the batch of igx_motion_amp_obs_steps), %d trajectories x %d history steps per fetch; "
+           "no host transfer, no synchronisation" % (nb, K))
     rec = TrajectoryRecorder(nb, K * 105, None, 4 * steps + WARMUP, dev)
 
     def fetch_and_stream(i):

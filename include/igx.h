@@ -702,6 +702,13 @@ int igx_motion_amp_obs_steps(const igx_motion_tables *t, const int64_t *motion_i
 int igx_motion_sample(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int64_t *motion_ids,
                       double *motion_times, igx_stream_t stream);
 
+/* fetch_amp_obs_demo (tasks/humanoid_amp.py:146-171) whole, in one launch: the draws of igx_motion_sample and the
+ * batch of igx_motion_amp_obs_steps on them.  out: [n, num_steps * 105]; motion_ids / motion_times (each may be NULL)
+ * receive the n draws.  Bit for bit what the two calls give one after the other with the same sampler. */
+int igx_motion_fetch_amp_obs(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int32_t num_steps,
+                             double step_dt, int32_t local_root_obs, float *out, int64_t *motion_ids, double *motion_times,
+                             igx_stream_t stream);
+
 typedef struct igx_amp_params {
     int32_t num_amp_obs_steps;        /* env.numAMPObsSteps >= 2 */
     int32_t local_root_obs;           /* env.localRootObs */

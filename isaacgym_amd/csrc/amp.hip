@@ -118,15 +118,32 @@ __device__ __forceinline__ void root_obs(f3 root_pos, f4 root_rot, f3 root_vel, 
     o[10] = la.x; o[11] = la.y; o[12] = la.z;
 }
 
+// MotionLib.sample_motions (motion_lib.py:61-65: np.random.choice(m, p=weights) = first index whose cumulative
+// weight exceeds a uniform draw) and sample_time (:67-78: uniform phase * motion length) from two of the four
+// uniforms of one Philox block
+__device__ __forceinline__ void draw_motion(const igx_motion_tables &t, const igx_motion_sampler &s, const float (&u)[4],
+                                            int64_t &id, double &time)
+{
+    const double pick = (double)u[0];
+    id = 0;
+    while (id < t.num_motions - 1 && !(pick < s.cdf[id])) ++id;
+    time = s.random_time ? (double)u[1] * t.motion_length[id] : 0.0;
+}
+
 // ---------------------------------------------------------------- motion state
-// 16 work items per sample: 0..11 dof joints, 12 root, 13 key bodies, 14/15 dof velocities
-template <bool AMP_OBS>
+// 16 work items per sample: 0..11 dof joints, 12 root, 13 key bodies, 14/15 dof velocities.
+// DRAW: ids / times are not inputs - every drawn sample (row / steps) takes its motion and time from the
+// sampler's Philox stream, as igx_motion_sample would have written them (and they are written out when the
+// pointers are given): a whole fetch_amp_obs_demo in one launch.
+template <bool AMP_OBS, bool DRAW = false>
 __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, const int64_t *__restrict__ ids,
                                                      const double *__restrict__ times, int64_t n,
                                                      const igx_motion_state_out o, int local_root_obs,
                                                      float *__restrict__ obs, const int64_t *__restrict__ out_rows,
                                                      int64_t out_row_stride, int64_t out_col_offset, int steps,
-                                                     double step_dt)
+                                                     double step_dt, const igx_motion_sampler sampler = {},
+                                                     int64_t *__restrict__ ids_out = nullptr,
+                                                     double *__restrict__ times_out = nullptr)
 {
     // a block owns 16 consecutive samples; thread t does work item t / 16 of sample t % 16, so that a wavefront
     // holds four item kinds x 16 samples: three of the block's four waves run the joint path only and one runs
@@ -137,9 +154,21 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
     // steps > 1: row s is history step k of drawn sample s / steps, at time t0 + (-dt * k) - the tiling of
     // fetch_amp_obs_demo (tasks/humanoid_amp.py:156-159) done here instead of on the host (fp64, same operations)
     const int64_t src = steps > 1 ? s / steps : s;
-    const int64_t id = ids[src];
-    if (id < 0 || id >= t.num_motions) return;  // not a motion: this sample's output rows are left as they are
-    double time = times[src];
+    int64_t id;
+    double time;
+    if constexpr (DRAW) {
+        float u[4];
+        philox_uniform4(sampler.seed, rng_offset_of(sampler.rng_offset, sampler.rng_offset_dev), src + sampler.env_offset, 0, u);
+        draw_motion(t, sampler, u, id, time);
+        if (item == 15 && s == src * steps) {  // one lane per drawn sample publishes the draw
+            if (ids_out) ids_out[src] = id;
+            if (times_out) times_out[src] = time;
+        }
+    } else {
+        id = ids[src];
+        if (id < 0 || id >= t.num_motions) return;  // not a motion: this sample's output rows are left as they are
+        time = times[src];
+    }
     if (steps > 1) time = time + (-step_dt * (double)(s - src * steps));
     const FrameBlend f = calc_frame_blend(t, id, time);
     float *orow = AMP_OBS ? obs + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset : nullptr;
@@ -597,10 +626,7 @@ __global__ __launch_bounds__(256) void motion_sample_flagged_kernel(const igx_mo
         float u[4];
         philox_uniform4(s.seed, rng_offset_of(s.rng_offset, s.rng_offset_dev), e + s.env_offset, 0, u);
         if (u[2] < s.ref_init_prob) {
-            const double pick = (double)u[0];
-            id = 0;
-            while (id < t.num_motions - 1 && !(pick < s.cdf[id])) ++id;
-            time = s.random_time ? (double)u[1] * t.motion_length[id] : 0.0;
+            draw_motion(t, s, u, id, time);
             env = e;
         } else {
             denv = e;
@@ -695,6 +721,27 @@ extern "C" int igx_motion_amp_obs_steps(const igx_motion_tables *t, const int64_
                        ids, times, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0, (int)num_steps,
                        step_dt);
     return launch_status("igx_motion_amp_obs_steps");
+}
+
+extern "C" int igx_motion_fetch_amp_obs(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int32_t num_steps,
+                                        double step_dt, int32_t local_root_obs, float *out, int64_t *motion_ids,
+                                        double *motion_times, igx_stream_t stream)
+{
+    const char *who = "igx_motion_fetch_amp_obs";
+    int rc = check_tables(t, who);
+    if (rc != IGX_OK) return rc;
+    if (!s) return fail(IGX_E_NULL, "%s: sampler struct is NULL", who);
+    if (num_steps < 1 || num_steps > 64) return fail(IGX_E_SIZE, "%s: num_steps %d", who, num_steps);
+    if (n < 0 || n > ((int64_t)1 << 32) / num_steps) return fail(IGX_E_SIZE, "%s: n out of range", who);
+    if (n == 0) return IGX_OK;
+    if (!s->cdf || !out) return fail(IGX_E_NULL, "%s: NULL argument", who);
+    igx_motion_state_out none = {};
+    const int64_t rows = n * num_steps;
+    const int64_t blocks = (rows * 16 + 255) / 256;
+    hipLaunchKernelGGL((motion_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
+                       nullptr, nullptr, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0, (int)num_steps,
+                       step_dt, *s, motion_ids, motion_times);
+    return launch_status(who);
 }
 
 extern "C" int igx_motion_sample(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int64_t *motion_ids,

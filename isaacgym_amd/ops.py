@@ -265,6 +265,30 @@ def motion_sample(tables, cdf, motion_ids, motion_times, random_time=True, seed=
     _lib.check(rc)
 
 
+def motion_fetch_amp_obs(tables, cdf, num_samples, num_steps, step_dt, local_root_obs, out, motion_ids=None,
+                         motion_times=None, random_time=True, seed=0, rng_offset=0, rng_offset_dev=None, env_offset=0):
+    """A whole fetch_amp_obs_demo in one launch: the draws of motion_sample and the batch of motion_amp_obs_steps on
+    them (bit for bit what the two calls give).  out: [num_samples, num_steps * 105]; motion_ids / motion_times, when
+    given, receive the draws."""
+    dev = out.device
+    n = int(num_samples)
+    if not out.is_contiguous() or out.numel() < n * num_steps * _abi.IGX_AMP_OBS:
+        raise ValueError("igx_motion_fetch_amp_obs: out must be contiguous and hold %d x %d x %d floats" %
+                         (n, num_steps, _abi.IGX_AMP_OBS))
+    for t in (motion_ids, motion_times):
+        if t is not None and t.shape[0] < n:
+            raise ValueError("igx_motion_fetch_amp_obs: motion_ids / motion_times shorter than num_samples")
+    s = _abi.MotionSampler(cdf=_lib.tensor_ptr(cdf, torch.float64), random_time=int(bool(random_time)), seed=int(seed),
+                           rng_offset=int(rng_offset), rng_offset_dev=rng_offset_dev, ref_init_prob=1.0,
+                           env_offset=int(env_offset))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_motion_fetch_amp_obs(C.byref(tables), C.byref(s), C.c_int64(n), C.c_int32(int(num_steps)),
+                                                 C.c_double(float(step_dt)), C.c_int32(int(bool(local_root_obs))),
+                                                 _lib.tensor_ptr(out, torch.float32), _lib.tensor_ptr(motion_ids, torch.int64),
+                                                 _lib.tensor_ptr(motion_times, torch.float64), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 def amp_observations(root_states, dof_pos, dof_vel, key_body_pos, local_root_obs, obs):
     dev = obs.device
     f = torch.float32

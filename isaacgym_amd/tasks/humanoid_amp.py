@@ -221,8 +221,9 @@ class HumanoidAMP(HumanoidAMPBase):
         return self._amp_obs_demo_buf.view(-1, self.get_num_amp_obs())
 
     def fetch_amp_obs_demo_device(self, num_samples, seed=0):
-        """fetch_amp_obs_demo with its two draws made on the device (MotionLib.sample_on_device): nothing crosses
-        the host link and nothing synchronises, so a fetch is two launches.  The distributions are the reference's
+        """fetch_amp_obs_demo with its two draws made on the device, inside the launch that builds the batch
+        (igx_motion_fetch_amp_obs; the draws are also left in self._demo_draws): nothing crosses the host link and
+        nothing synchronises, a fetch is one launch.  The distributions are the reference's
         (motion by weight, uniform phase); the random stream is the library's Philox, keyed by (seed, fetch count,
         sample index), not numpy's - use fetch_amp_obs_demo to reproduce a numpy-seeded sequence."""
         if self._amp_obs_demo_buf is None:
@@ -234,9 +235,9 @@ class HumanoidAMP(HumanoidAMPBase):
             w = self._demo_draws = (torch.empty(num_samples, dtype=torch.int64, device=self.device),
                                     torch.empty(num_samples, dtype=torch.float64, device=self.device))
         self._demo_fetches = self.__dict__.get("_demo_fetches", 0) + 1
-        self._motion_lib.sample_on_device(num_samples, seed, self._demo_fetches, out=w)
-        ops.motion_amp_obs_steps(self._motion_lib._tables, w[0], w[1], self._num_amp_obs_steps, self.dt,
-                                 self._local_root_obs, self._amp_obs_demo_buf)
+        ops.motion_fetch_amp_obs(self._motion_lib._tables, self._motion_lib.sampling_cdf(), num_samples,
+                                 self._num_amp_obs_steps, self.dt, self._local_root_obs, self._amp_obs_demo_buf,
+                                 motion_ids=w[0], motion_times=w[1], seed=seed, rng_offset=self._demo_fetches)
         return self._amp_obs_demo_buf.view(-1, self.get_num_amp_obs())
 
     def stream_amp_obs_demo(self, recorder, num_samples, device_sampling=True, seed=0):

@@ -188,13 +188,13 @@ def motion_amp_obs_steps(tabs, ids, times, num_steps, step_dt, local_root_obs):
     return out
 
 
-def motion_sample(tabs, cdf, n, random_time, seed, rng_offset):
+def motion_sample(tabs, cdf, n, random_time, seed, rng_offset, env_offset=0):
     """(motion_ids, motion_times), each [n]: the library's device-side sample_motions + sample_time."""
     cdf = np.ascontiguousarray(cdf, np.float64)
     ids, times = np.zeros(n, np.int64), np.zeros(n, np.float64)
     t = motion_tables(tabs)
     s = _abi.MotionSampler(cdf=cdf.ctypes.data, random_time=int(random_time), ref_init_prob=1.0, seed=seed,
-                           rng_offset=rng_offset)
+                           rng_offset=rng_offset, env_offset=env_offset)
     assert lib().orc_motion_sample(C.byref(t), C.byref(s), C.c_int64(n), C.c_void_p(ids.ctypes.data),
                                    C.c_void_p(times.ctypes.data)) == 0
     return ids, times

@@ -136,6 +136,35 @@ def test_device_sampler_equals_the_checker(motion):
         assert np.array_equal(host(ids), want[0]) and np.array_equal(host(times), want[1])
 
 
+@pytest.mark.parametrize("n,K,local_root_obs,random_time", [(0, 2, False, True), (1, 1, True, True), (15, 3, False, True),
+                                                            (512, 2, False, True), (4097, 2, True, False),
+                                                            (100003, 4, False, True)])
+def test_fused_fetch_equals_draws_then_batch(motion, n, K, local_root_obs, random_time):
+    """igx_motion_fetch_amp_obs (a whole fetch_amp_obs_demo in one launch) against igx_motion_sample followed by
+    igx_motion_amp_obs_steps with the same sampler: the draws and the batch bit for bit, and the draws against the
+    CPU checker's restatement of the sampler; with and without the draws written out."""
+    g, tabs_np, tabs_dev, tables = motion
+    cdf = np.cumsum(g["motion_weights"]) / np.sum(g["motion_weights"])
+    dt = 0.0332
+    ids, times = torch.empty(n, dtype=torch.int64, device=DEV), torch.empty(n, dtype=torch.float64, device=DEV)
+    two = torch.full((n, K * 105), 3.0, device=DEV)
+    ops.motion_sample(tables, dev(cdf), ids, times, random_time=random_time, seed=31, rng_offset=7, env_offset=11)
+    ops.motion_amp_obs_steps(tables, ids, times, K, dt, local_root_obs, two)
+    one = torch.full((n, K * 105), 5.0, device=DEV)
+    ids1, times1 = torch.full_like(ids, -9), torch.full_like(times, -9.0)
+    ops.motion_fetch_amp_obs(tables, dev(cdf), n, K, dt, local_root_obs, one, ids1, times1, random_time=random_time,
+                             seed=31, rng_offset=7, env_offset=11)
+    assert torch.equal(ids1, ids) and torch.equal(times1, times)
+    assert torch.equal(one, two)
+    if n:
+        want = oracle.motion_sample(tabs_np, cdf, n, random_time, seed=31, rng_offset=7, env_offset=11)
+        assert np.array_equal(host(ids1), want[0]) and np.array_equal(host(times1), want[1])
+    silent = torch.full((n, K * 105), 7.0, device=DEV)
+    ops.motion_fetch_amp_obs(tables, dev(cdf), n, K, dt, local_root_obs, silent, random_time=random_time, seed=31,
+                             rng_offset=7, env_offset=11)
+    assert torch.equal(silent, two)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 4097, 200000])
 def test_motion_state_vs_oracle(motion, n):
     _, tabs_np, _, tables = motion
