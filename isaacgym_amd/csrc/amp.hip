@@ -558,7 +558,7 @@ __global__ __launch_bounds__(WAVE) void amp_step_pair_kernel(const igx_amp_param
     // ---- AMP history
     float *amp = b.amp_obs + base * K * NO;
     if (KK != 0 && full && dev_aligned16(b.amp_obs)) {
-        constexpr int G = 16;
+        constexpr int G = 16;  // 8 rows per group: 577 us, 32 (one round trip per tile): 561 us, 16: 558-560 us at 2^20 envs
 #pragma unroll 1
         for (int g0 = 0; g0 < T; g0 += G) shift_history<KK ? KK : 2, G>(amp, s_tile, g0, lane);
     } else {
