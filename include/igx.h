@@ -694,6 +694,17 @@ int igx_motion_amp_obs(const igx_motion_tables *t, const int64_t *motion_ids, co
 int igx_motion_amp_obs_steps(const igx_motion_tables *t, const int64_t *motion_ids, const double *motion_times, int64_t n,
                              int32_t num_steps, double step_dt, int32_t local_root_obs, float *out, igx_stream_t stream);
 
+/* The AMP history of environments that were reset to a reference motion (HumanoidAMP._init_amp_obs_ref,
+ * tasks/humanoid_amp.py:279-294): for list entry i < n and history step k, first_step <= k < num_steps, the observation
+ * of motion_ids[i] at motion_times[i] + (-step_dt * k) is written to row (env_ids ? env_ids[i] : i) * num_steps + k of
+ * amp_obs [num_envs, num_steps, 105].  The reference fills steps 1 ... num_steps - 1 (first_step = 1; step 0 is the
+ * environment's own observation).  Entries with a motion id outside [0, num_motions) are holes and are skipped (the
+ * masked lists of igx_motion_sample_flagged).  Equals igx_motion_amp_obs on the tiled lists with explicit rows, bit
+ * for bit, without the tiling on the host. */
+int igx_motion_amp_obs_history(const igx_motion_tables *t, const int64_t *motion_ids, const double *motion_times,
+                               const int64_t *env_ids, int64_t n, int32_t num_steps, int32_t first_step, double step_dt,
+                               int32_t local_root_obs, float *amp_obs, igx_stream_t stream);
+
 /* The two draws of fetch_amp_obs_demo on the device (MotionLib.sample_motions / sample_time,
  * tasks/amp/utils_amp/motion_lib.py:61-78): motion_ids[i] = first j with u0 < cdf[j], motion_times[i] = u1 * length
  * (0 with random_time == 0), u0 / u1 from the Philox stream keyed by (seed, rng_offset, i + env_offset) as in

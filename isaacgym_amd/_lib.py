@@ -83,6 +83,7 @@ SYMBOLS.update({
     "igx_motion_sample": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     "igx_motion_amp_obs_steps": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_int32, _P, _P]),
     "igx_motion_fetch_amp_obs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_double, C.c_int32, _P, _P, _P, _P]),
+    "igx_motion_amp_obs_history": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P]),
     "igx_humanoid_amp_reset": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
 })
 # batched torch_jit_utils math: (inputs..., out, n[, d], stream)

@@ -130,6 +130,16 @@ __device__ __forceinline__ void draw_motion(const igx_motion_tables &t, const ig
     time = s.random_time ? (double)u[1] * t.motion_length[id] : 0.0;
 }
 
+// How the rows of a launch map to drawn samples when the kernel tiles over history steps (steps == 0: it does
+// not, row s is sample s): row s is step first + s % steps of sample s / steps, evaluated at the sample's time
+// + (-dt * step) - the fp64 operations of tasks/humanoid_amp.py:156-159 and :283-284 - and written to output
+// row (envs ? envs[sample] : sample) * row_steps + step.
+struct StepTiling {
+    int steps, first, row_steps;
+    double dt;
+    const int64_t *envs;
+};
+
 // ---------------------------------------------------------------- motion state
 // 16 work items per sample: 0..11 dof joints, 12 root, 13 key bodies, 14/15 dof velocities.
 // DRAW: ids / times are not inputs - every drawn sample (row / steps) takes its motion and time from the
@@ -140,8 +150,8 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
                                                      const double *__restrict__ times, int64_t n,
                                                      const igx_motion_state_out o, int local_root_obs,
                                                      float *__restrict__ obs, const int64_t *__restrict__ out_rows,
-                                                     int64_t out_row_stride, int64_t out_col_offset, int steps,
-                                                     double step_dt, const igx_motion_sampler sampler = {},
+                                                     int64_t out_row_stride, int64_t out_col_offset,
+                                                     const StepTiling tile = {}, const igx_motion_sampler sampler = {},
                                                      int64_t *__restrict__ ids_out = nullptr,
                                                      double *__restrict__ times_out = nullptr)
 {
@@ -153,14 +163,15 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
     if (s >= n) return;
     // steps > 1: row s is history step k of drawn sample s / steps, at time t0 + (-dt * k) - the tiling of
     // fetch_amp_obs_demo (tasks/humanoid_amp.py:156-159) done here instead of on the host (fp64, same operations)
-    const int64_t src = steps > 1 ? s / steps : s;
+    const int64_t src = tile.steps ? s / tile.steps : s;
+    const int step = tile.steps ? tile.first + (int)(s - src * tile.steps) : 0;
     int64_t id;
     double time;
     if constexpr (DRAW) {
         float u[4];
         philox_uniform4(sampler.seed, rng_offset_of(sampler.rng_offset, sampler.rng_offset_dev), src + sampler.env_offset, 0, u);
         draw_motion(t, sampler, u, id, time);
-        if (item == 15 && s == src * steps) {  // one lane per drawn sample publishes the draw
+        if (item == 15 && s == src * tile.steps) {  // one lane per drawn sample publishes the draw
             if (ids_out) ids_out[src] = id;
             if (times_out) times_out[src] = time;
         }
@@ -169,9 +180,13 @@ __global__ __launch_bounds__(256) void motion_kernel(const igx_motion_tables t, 
         if (id < 0 || id >= t.num_motions) return;  // not a motion: this sample's output rows are left as they are
         time = times[src];
     }
-    if (steps > 1) time = time + (-step_dt * (double)(s - src * steps));
+    int64_t row = out_rows ? out_rows[s] : s;
+    if (tile.steps) {
+        time = time + (-tile.dt * (double)step);
+        row = (tile.envs ? tile.envs[src] : src) * tile.row_steps + step;
+    }
     const FrameBlend f = calc_frame_blend(t, id, time);
-    float *orow = AMP_OBS ? obs + (out_rows ? out_rows[s] : s) * out_row_stride + out_col_offset : nullptr;
+    float *orow = AMP_OBS ? obs + row * out_row_stride + out_col_offset : nullptr;
 
     if (item < 12) {
         // items 0..7 are the eight 3-dof joints, 8..11 the four hinges (a nibble table: no memory access), so a
@@ -734,7 +749,7 @@ extern "C" int igx_motion_state(const igx_motion_tables *t, const int64_t *ids, 
     if (!ids || !times || !out) return fail(IGX_E_NULL, "igx_motion_state: NULL argument");
     const int64_t blocks = (n * 16 + 255) / 256;
     hipLaunchKernelGGL((motion_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
-                       ids, times, n, *out, 0, nullptr, nullptr, (int64_t)0, (int64_t)0, 1, 0.0);
+                       ids, times, n, *out, 0, nullptr, nullptr, (int64_t)0, (int64_t)0);
     return launch_status("igx_motion_state");
 }
 
@@ -751,7 +766,7 @@ extern "C" int igx_motion_amp_obs(const igx_motion_tables *t, const int64_t *ids
     igx_motion_state_out none = {};
     const int64_t blocks = (n * 16 + 255) / 256;
     hipLaunchKernelGGL((motion_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
-                       ids, times, n, none, (int)local_root_obs, out, out_rows, out_row_stride, out_col_offset, 1, 0.0);
+                       ids, times, n, none, (int)local_root_obs, out, out_rows, out_row_stride, out_col_offset);
     return launch_status("igx_motion_amp_obs");
 }
 
@@ -769,9 +784,31 @@ extern "C" int igx_motion_amp_obs_steps(const igx_motion_tables *t, const int64_
     const int64_t rows = n * num_steps;
     const int64_t blocks = (rows * 16 + 255) / 256;
     hipLaunchKernelGGL((motion_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
-                       ids, times, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0, (int)num_steps,
-                       step_dt);
+                       ids, times, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0,
+                       StepTiling{(int)num_steps, 0, (int)num_steps, step_dt, nullptr});
     return launch_status("igx_motion_amp_obs_steps");
+}
+
+extern "C" int igx_motion_amp_obs_history(const igx_motion_tables *t, const int64_t *ids, const double *times,
+                                          const int64_t *env_ids, int64_t n, int32_t num_steps, int32_t first_step,
+                                          double step_dt, int32_t local_root_obs, float *amp_obs, igx_stream_t stream)
+{
+    const char *who = "igx_motion_amp_obs_history";
+    int rc = check_tables(t, who);
+    if (rc != IGX_OK) return rc;
+    if (num_steps < 1 || num_steps > 64 || first_step < 0 || first_step >= num_steps)
+        return fail(IGX_E_SIZE, "%s: num_steps %d, first_step %d", who, num_steps, first_step);
+    if (n < 0 || n > ((int64_t)1 << 32) / num_steps) return fail(IGX_E_SIZE, "%s: n out of range", who);
+    if (n == 0) return IGX_OK;
+    if (!ids || !times || !amp_obs) return fail(IGX_E_NULL, "%s: NULL argument", who);
+    igx_motion_state_out none = {};
+    const int per = num_steps - first_step;
+    const int64_t rows = n * per;
+    const int64_t blocks = (rows * 16 + 255) / 256;
+    hipLaunchKernelGGL((motion_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
+                       ids, times, rows, none, (int)local_root_obs, amp_obs, nullptr, (int64_t)NO, (int64_t)0,
+                       StepTiling{per, (int)first_step, (int)num_steps, step_dt, env_ids});
+    return launch_status(who);
 }
 
 extern "C" int igx_motion_fetch_amp_obs(const igx_motion_tables *t, const igx_motion_sampler *s, int64_t n, int32_t num_steps,
@@ -790,8 +827,8 @@ extern "C" int igx_motion_fetch_amp_obs(const igx_motion_tables *t, const igx_mo
     const int64_t rows = n * num_steps;
     const int64_t blocks = (rows * 16 + 255) / 256;
     hipLaunchKernelGGL((motion_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *t,
-                       nullptr, nullptr, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0, (int)num_steps,
-                       step_dt, *s, motion_ids, motion_times);
+                       nullptr, nullptr, rows, none, (int)local_root_obs, out, nullptr, (int64_t)NO, (int64_t)0,
+                       StepTiling{(int)num_steps, 0, (int)num_steps, step_dt, nullptr}, *s, motion_ids, motion_times);
     return launch_status(who);
 }
 

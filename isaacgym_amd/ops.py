@@ -265,6 +265,30 @@ def motion_sample(tables, cdf, motion_ids, motion_times, random_time=True, seed=
     _lib.check(rc)
 
 
+def motion_amp_obs_history(tables, motion_ids, motion_times, env_ids, num_steps, step_dt, local_root_obs, amp_obs,
+                           first_step=1):
+    """History slots first_step ... num_steps - 1 of amp_obs [num_envs, num_steps, 105] for the listed environments
+    (env_ids None: entry i is environment i) from their reference motions at motion_times - step_dt * k; entries
+    whose motion id is negative are skipped."""
+    dev = amp_obs.device
+    n = motion_ids.shape[0]
+    if motion_times.shape[0] != n or (env_ids is not None and env_ids.shape[0] != n):
+        raise ValueError("igx_motion_amp_obs_history: the lists differ in length")
+    if not amp_obs.is_contiguous() or amp_obs.numel() % (num_steps * _abi.IGX_AMP_OBS):
+        raise ValueError("igx_motion_amp_obs_history: amp_obs must be a contiguous [num_envs, %d, %d] buffer" %
+                         (num_steps, _abi.IGX_AMP_OBS))
+    if env_ids is None and amp_obs.numel() < n * num_steps * _abi.IGX_AMP_OBS:
+        raise ValueError("igx_motion_amp_obs_history: amp_obs holds fewer environments than the lists")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().igx_motion_amp_obs_history(C.byref(tables), _lib.tensor_ptr(motion_ids, torch.int64),
+                                                   _lib.tensor_ptr(motion_times, torch.float64),
+                                                   _lib.tensor_ptr(env_ids, torch.int64), C.c_int64(n),
+                                                   C.c_int32(int(num_steps)), C.c_int32(int(first_step)),
+                                                   C.c_double(float(step_dt)), C.c_int32(int(bool(local_root_obs))),
+                                                   _lib.tensor_ptr(amp_obs, torch.float32), _lib.current_stream(dev))
+    _lib.check(rc)
+
+
 def motion_fetch_amp_obs(tables, cdf, num_samples, num_steps, step_dt, local_root_obs, out, motion_ids=None,
                          motion_times=None, random_time=True, seed=0, rng_offset=0, rng_offset_dev=None, env_offset=0):
     """A whole fetch_amp_obs_demo in one launch: the draws of motion_sample and the batch of motion_amp_obs_steps on

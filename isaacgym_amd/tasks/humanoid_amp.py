@@ -322,8 +322,7 @@ class HumanoidAMP(HumanoidAMPBase):
                 state=dict(root_pos=torch.empty(n, 3, **f32), root_rot=torch.empty(n, 4, **f32),
                            dof_pos=torch.empty(n, 28, **f32), root_vel=torch.empty(n, 3, **f32),
                            root_ang_vel=torch.empty(n, 3, **f32), dof_vel=torch.empty(n, 28, **f32)),
-                rows=(torch.arange(n, device=dev).unsqueeze(-1) * K + 1 + torch.arange(K - 1, device=dev)).flatten().contiguous(),
-                back=-self.dt * (torch.arange(K - 1, device=dev, dtype=torch.float64) + 1), draws=0)
+                draws=0)
         w["draws"] += 1
         ops.motion_sample_flagged(lib._tables, lib.sampling_cdf(), self.reset_buf, w["env_ids"], w["ids"], w["times"],
                                   random_time=self._state_init in (SI.Random, SI.Hybrid), seed=seed,
@@ -337,11 +336,8 @@ class HumanoidAMP(HumanoidAMPBase):
             return self._publish_obs()
         ops.motion_state(lib._tables, w["ids"], w["times"], w["state"])
         ops.humanoid_amp_reset(self._params(), self._buffers(), w["env_ids"], w["state"])
-        # the history slots: the same motions at times - dt, - 2 dt, ... (humanoid_amp.py:279-294)
-        hist_ids = w["ids"].unsqueeze(-1).expand(n, K - 1).reshape(-1).contiguous()
-        hist_times = (w["times"].unsqueeze(-1) + w["back"]).reshape(-1).contiguous()
-        ops.motion_amp_obs(lib._tables, hist_ids, hist_times, self._local_root_obs, self._amp_obs_buf, out_rows=w["rows"],
-                           out_row_stride=NUM_AMP_OBS_PER_STEP)
+        # the history slots: the same motions at times - dt, - 2 dt, ... (humanoid_amp.py:279-294), tiled in the kernel
+        ops.motion_amp_obs_history(lib._tables, w["ids"], w["times"], None, K, self.dt, self._local_root_obs, self._amp_obs_buf)
         self.sim.notify_root_state(self._root_states, None)
         self.sim.notify_dof_state(None)
         return self._publish_obs()
@@ -365,9 +361,8 @@ class HumanoidAMP(HumanoidAMPBase):
         self._hist_amp_obs_buf[env_ids] = self._curr_amp_obs_buf[env_ids].unsqueeze(-2)
 
     def _init_amp_obs_ref(self, env_ids, motion_ids, motion_times):  # humanoid_amp.py:279-294
-        K = self._num_amp_obs_steps
-        motion_ids = np.tile(np.expand_dims(motion_ids, axis=-1), [1, K - 1])
-        motion_times = np.expand_dims(motion_times, axis=-1) + (-self.dt * (np.arange(0, K - 1) + 1))
-        rows = (env_ids.unsqueeze(-1) * K + 1 + torch.arange(0, K - 1, device=self.device)).flatten().contiguous()
-        self._motion_lib.get_amp_obs(motion_ids.flatten(), motion_times.flatten(), self._local_root_obs,
-                                     out=self._amp_obs_buf, out_rows=rows, out_row_stride=NUM_AMP_OBS_PER_STEP)
+        # the np.tile of the ids and `times - dt * (arange(K - 1) + 1)` of the reference happen in the kernel: the host
+        # sends one id and one time per reset environment
+        ids, times = self._motion_lib._to_device(motion_ids, motion_times)
+        ops.motion_amp_obs_history(self._motion_lib._tables, ids, times, env_ids, self._num_amp_obs_steps, self.dt,
+                                   self._local_root_obs, self._amp_obs_buf)

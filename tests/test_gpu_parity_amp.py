@@ -165,6 +165,37 @@ def test_fused_fetch_equals_draws_then_batch(motion, n, K, local_root_obs, rando
     assert torch.equal(silent, two)
 
 
+@pytest.mark.parametrize("m,K,compact", [(0, 2, True), (1, 2, True), (17, 3, True), (3000, 2, True), (5000, 4, False),
+                                         (70000, 2, False)])
+def test_history_entry_equals_tiled_lists(motion, m, K, compact):
+    """igx_motion_amp_obs_history (the tiling of HumanoidAMP._init_amp_obs_ref in the kernel) against
+    igx_motion_amp_obs on the host-tiled lists with explicit rows: bit for bit; a compact list with environment
+    ids, and a masked list (entry i = environment i, -1 holes) as igx_motion_sample_flagged leaves it."""
+    g, tabs_np, tabs_dev, tables = motion
+    rng = np.random.default_rng(m + K)
+    num_envs = 3 * m + 5 if compact else m
+    dt = 0.0332
+    ids = rng.integers(0, 2, m).astype(np.int64)
+    times = rng.uniform(0.0, 1.0, m) * tabs_np["motion_length"][ids]
+    if compact:
+        envs = np.sort(rng.choice(num_envs, m, replace=False)).astype(np.int64)
+        keep = np.ones(m, bool)
+    else:
+        envs = np.arange(m, dtype=np.int64)
+        keep = rng.random(m) < 0.05
+        ids = np.where(keep, ids, -1)
+    want = torch.full((num_envs, K, 105), 9.0, device=DEV)
+    t_ids = np.tile(np.expand_dims(ids[keep], -1), [1, K - 1]).flatten()
+    t_times = (np.expand_dims(times[keep], -1) + (-dt * (np.arange(0, K - 1) + 1))).flatten()
+    rows = (np.expand_dims(envs[keep], -1) * K + 1 + np.arange(0, K - 1)).flatten()
+    if len(t_ids):
+        ops.motion_amp_obs(tables, dev(t_ids), dev(t_times), True, want, out_rows=dev(rows), out_row_stride=105)
+    got = torch.full((num_envs, K, 105), 9.0, device=DEV)
+    ops.motion_amp_obs_history(tables, dev(ids), dev(times), dev(envs) if compact else None, K, dt, True, got)
+    assert torch.equal(got, want)
+    assert bool((got[:, 0] == 9.0).all())  # step 0 is the environment's own observation: not touched
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 4097, 200000])
 def test_motion_state_vs_oracle(motion, n):
     _, tabs_np, _, tables = motion
