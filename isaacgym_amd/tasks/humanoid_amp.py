@@ -11,10 +11,12 @@ sampling (same generator, same draws as the reference).
 import os
 from enum import Enum
 
+import ctypes as C
+
 import numpy as np
 import torch
 
-from .. import _abi, ops
+from .. import _abi, _lib, ops
 from .amp.utils_amp.motion_lib import DOF_OFFSETS, MotionLib
 from .base.vec_task import VecTask
 
@@ -324,6 +326,8 @@ class HumanoidAMP(HumanoidAMPBase):
                            root_ang_vel=torch.empty(n, 3, **f32), dof_vel=torch.empty(n, 28, **f32)),
                 draws=0)
         w["draws"] += 1
+        if self._run_flagged_plan(w, seed, ref_prob):
+            return self._publish_obs()
         ops.motion_sample_flagged(lib._tables, lib.sampling_cdf(), self.reset_buf, w["env_ids"], w["ids"], w["times"],
                                   random_time=self._state_init in (SI.Random, SI.Hybrid), seed=seed,
                                   rng_offset=w["draws"], rng_offset_dev=self._rng_dev(), ref_init_prob=ref_prob, env_offset=self.env_offset,
@@ -333,6 +337,7 @@ class HumanoidAMP(HumanoidAMPBase):
                                    dict(dof_pos=self._initial_dof_pos, dof_vel=self._initial_dof_vel))
         if ref_prob <= 0.0:
             self.sim.notify_dof_state(None)
+            self._build_flagged_plan(w, seed, ref_prob)
             return self._publish_obs()
         ops.motion_state(lib._tables, w["ids"], w["times"], w["state"])
         ops.humanoid_amp_reset(self._params(), self._buffers(), w["env_ids"], w["state"])
@@ -340,7 +345,70 @@ class HumanoidAMP(HumanoidAMPBase):
         ops.motion_amp_obs_history(lib._tables, w["ids"], w["times"], None, K, self.dt, self._local_root_obs, self._amp_obs_buf)
         self.sim.notify_root_state(self._root_states, None)
         self.sim.notify_dof_state(None)
+        self._build_flagged_plan(w, seed, ref_prob)
         return self._publish_obs()
+
+    def _build_flagged_plan(self, w, seed, ref_prob):
+        """After a first reset_flagged() went through the checked calls: the argument structs of the same launches,
+        kept for the calls that follow (the buffers are this task's own, and the plan is dropped as soon as one of
+        them points elsewhere).  A later call then costs the launches and one field store."""
+        SI = HumanoidAMP.StateInit
+        lib, ml, n, K = _lib.lib(), self._motion_lib, self.num_envs, self._num_amp_obs_steps
+        sampler = _abi.MotionSampler(cdf=_lib.tensor_ptr(ml.sampling_cdf(), torch.float64),
+                                     random_time=int(self._state_init in (SI.Random, SI.Hybrid)), seed=int(seed),
+                                     rng_offset=0, rng_offset_dev=self._rng_dev(), ref_init_prob=float(ref_prob),
+                                     env_offset=int(self.env_offset))
+        default_state = dict(dof_pos=self._initial_dof_pos, dof_vel=self._initial_dof_vel)
+        bufs = self._buffers()
+        amp_b, dev = _lib.make_buffers(_abi.AmpBuffers, bufs)
+        st_ref, _ = _lib.make_buffers(_abi.MotionStateOut, w["state"])
+        st_def, _ = _lib.make_buffers(_abi.MotionStateOut, default_state)
+        held = _lib._held([ml.sampling_cdf(), self.reset_buf, w["env_ids"], w["ids"], w["times"], w["default_ids"]] +
+                          list(bufs.values()) + list(w["state"].values()) + list(default_state.values()))
+        ptr = lambda t, dt: _lib.tensor_ptr(t, dt)  # noqa: E731
+        i64, f64, f32, cn = torch.int64, torch.float64, torch.float32, C.c_int64(n)
+        params = self._params()
+        calls = [(lib.igx_motion_sample_flagged, (C.byref(ml._tables), C.byref(sampler), ptr(self.reset_buf, i64), cn,
+                                                  ptr(w["env_ids"], i64), ptr(w["ids"], i64), ptr(w["times"], f64),
+                                                  ptr(w["default_ids"], i64)))]
+        if ref_prob < 1.0:
+            calls.append((lib.igx_humanoid_amp_reset, (C.byref(params), C.byref(amp_b), ptr(w["default_ids"], i64), cn,
+                                                       C.byref(st_def))))
+        if ref_prob > 0.0:
+            calls.append((lib.igx_motion_state, (C.byref(ml._tables), ptr(w["ids"], i64), ptr(w["times"], f64), cn,
+                                                 C.byref(st_ref))))
+            calls.append((lib.igx_humanoid_amp_reset, (C.byref(params), C.byref(amp_b), ptr(w["env_ids"], i64), cn,
+                                                       C.byref(st_ref))))
+            calls.append((lib.igx_motion_amp_obs_history, (C.byref(ml._tables), ptr(w["ids"], i64), ptr(w["times"], f64), None,
+                                                           cn, C.c_int32(K), C.c_int32(1), C.c_double(float(self.dt)),
+                                                           C.c_int32(int(bool(self._local_root_obs))),
+                                                           ptr(self._amp_obs_buf, f32))))
+        w["plan"] = dict(key=self._flagged_plan_key(seed, ref_prob), calls=calls, sampler=sampler, dev=dev, held=held,
+                         ptrs=_lib._pointers(held), storages=_lib._storages(held), keep=(params, amp_b, st_ref, st_def))
+
+    def _flagged_plan_key(self, seed, ref_prob):
+        """Everything the plan's structs were filled from: the tensor objects behind the buffer names (a name bound
+        to another tensor is another buffer; where each object points is compared separately) and the parameters."""
+        return (tuple(map(id, self._buffers().values())), id(self._initial_dof_pos), id(self._initial_dof_vel),
+                int(seed), float(ref_prob), self._state_init, self._rng_dev(), self.env_offset, self._num_amp_obs_steps,
+                float(self.dt), bool(self._local_root_obs), tuple(self._kb), tuple(self._cb),
+                bool(self._enable_early_termination), float(self._termination_height), int(self.max_episode_length))
+
+    def _run_flagged_plan(self, w, seed, ref_prob):
+        plan = w.get("plan")
+        if plan is None:
+            return False
+        if plan["key"] != self._flagged_plan_key(seed, ref_prob) or _lib._pointers(plan["held"]) != plan["ptrs"]:
+            w["plan"] = None  # something the structs were built from has changed: back through the checked calls
+            return False
+        plan["sampler"].rng_offset = w["draws"]
+        dev = plan["dev"]
+        for fn, args in plan["calls"]:
+            _lib.check(_lib._launch(fn, dev, *args))
+        if ref_prob > 0.0:
+            self.sim.notify_root_state(self._root_states, None)
+        self.sim.notify_dof_state(None)
+        return True
 
     def _set_env_state(self, env_ids, root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel):
         state = dict(root_pos=root_pos, root_rot=root_rot, dof_pos=dof_pos, root_vel=root_vel,

@@ -401,6 +401,41 @@ def test_ant_with_randomization_noise():
     assert noisy.last_rand_step >= 0 and not noisy.first_randomization
 
 
+@pytest.mark.parametrize("state_init", ["Random", "Hybrid", "Default"])
+def test_amp_reset_flagged_kept_plan_equals_the_checked_calls(motion_lib, state_init):
+    """After its first call reset_flagged() replays kept argument structs.  A twin that is made to go through
+    the checked calls every time must end up with the same tensors call after call - also after a buffer of the
+    task was bound to other memory and after a parameter changed, both of which drop the plan."""
+    n = 3000
+    a, b = (_amp_task(motion_lib, n, stateInit=state_init) for _ in range(2))
+    zero = torch.zeros(n, 28, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+
+    def same(call):
+        for k in ("_root_states", "_dof_state", "_amp_obs_buf", "obs_buf", "progress_buf", "reset_buf", "_terminate_buf"):
+            x, y = getattr(a, k), getattr(b, k)
+            rows = (x != y).reshape(n, -1).any(-1).nonzero().flatten()
+            assert rows.numel() == 0, (k, call, rows[:8].tolist(), a._flagged_ws["ids"][rows[:8]].tolist(),
+                                       b._flagged_ws["ids"][rows[:8]].tolist())
+
+    for call in range(7):
+        flags = (torch.rand(n, device=DEV, generator=gen) < 0.2).to(torch.int64)
+        if call == 3:    # another tensor object behind a buffer name: the plan's pointers no longer hold
+            a.reset_buf = a.reset_buf.clone()
+        if call == 5:    # a parameter the structs were filled from
+            a._local_root_obs = b._local_root_obs = not a._local_root_obs
+        for t in (a, b):
+            t.step(zero)
+            t.reset_buf.copy_(flags)
+        had_plan = a._flagged_ws.get("plan") is not None if call else False
+        a.reset_flagged(seed=5)
+        b.reset_flagged(seed=5)
+        b._flagged_ws["plan"] = None  # the twin never replays
+        assert had_plan == (call not in (0,)), call
+        assert a._flagged_ws.get("plan") is not None
+        same(call)
+
+
 @pytest.mark.parametrize("state_init", ["Random", "Start", "Hybrid", "Default"])
 def test_amp_reset_flagged_equals_the_host_path_on_the_same_draws(motion_lib, state_init):
     """reset_flagged() never leaves the device.  Its draws (read back here) fed through the host path
