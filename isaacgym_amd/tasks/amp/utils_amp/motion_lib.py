@@ -320,6 +320,14 @@ class MotionLib:
 
     # ---- loading ------------------------------------------------------------
     def _to_device(self, motion_ids, motion_times):
+        if not torch.is_tensor(motion_ids) and not torch.is_tensor(motion_times):  # the reference's case: numpy draws
+            ids = np.ascontiguousarray(motion_ids, dtype=np.int64)
+            times = np.ascontiguousarray(motion_times, dtype=np.float64)
+            if ids.shape != times.shape or ids.ndim != 1:
+                raise ValueError("motion_ids and motion_times must be 1-D and of equal length")
+            if ids.size and (int(ids.min()) < 0 or int(ids.max()) >= self.num_motions()):
+                raise IndexError("motion id out of range")
+            return self._stage(ids, times)
         ids = torch.as_tensor(np.ascontiguousarray(motion_ids, dtype=np.int64)) if not torch.is_tensor(motion_ids) \
             else motion_ids.to(torch.int64)
         times = torch.as_tensor(np.ascontiguousarray(motion_times, dtype=np.float64)) \
@@ -329,6 +337,39 @@ class MotionLib:
         if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.num_motions()):
             raise IndexError("motion id out of range")
         return ids.to(self._device).contiguous(), times.to(self._device).contiguous()
+
+    _STAGE_SLOTS = 4
+
+    def _stage(self, ids, times):
+        """Host draws to the device through pinned memory: ids and times side by side in one slot of a small ring,
+        one asynchronous copy (two blocking copies out of pageable memory cost 28 of a fetch's 59 us).  The device
+        tensors returned are views of the slot: good for the launches the caller enqueues next, overwritten (in
+        stream order) once the ring has come round."""
+        n = int(ids.shape[0])
+        dev = self._device
+        if n == 0:
+            return torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float64, device=dev)
+        ring = self.__dict__.get("_stage_ring")
+        if ring is None or ring["cap"] < n:
+            cap = max(1024, 1 << (n - 1).bit_length())
+            slots = []
+            for _ in range(self._STAGE_SLOTS):
+                host = torch.empty(2 * cap, dtype=torch.int64, pin_memory=True)
+                slots.append(dict(host=host, view=host.numpy(), dev=torch.empty(2 * cap, dtype=torch.int64, device=dev),
+                                  event=None))
+            ring = self._stage_ring = dict(cap=cap, next=0, slots=slots)
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % self._STAGE_SLOTS
+        if slot["event"] is not None:
+            slot["event"].synchronize()  # the copy that last read this slot's host memory (four fetches ago)
+        slot["view"][:n] = ids
+        slot["view"][n:2 * n].view(np.float64)[:] = times
+        with torch.cuda.device(dev):
+            slot["dev"][:2 * n].copy_(slot["host"][:2 * n], non_blocking=True)
+            if slot["event"] is None:
+                slot["event"] = torch.cuda.Event()
+            slot["event"].record()
+        return slot["dev"][:n], slot["dev"][n:2 * n].view(torch.float64)
 
     def _fetch_motion_files(self, motion_file):  # motion_lib.py:208-231
         ext = os.path.splitext(motion_file)[1]
