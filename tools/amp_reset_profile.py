@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Host profile of HumanoidAMP.reset_flagged at 4 096 environments.  Usage (repository root): python tools/amp_reset_profile.py"""
+"""Host profile of HumanoidAMP.reset_flagged (or, with the argument `done`, reset_done) at 4 096 environments.
+Usage (repository root): python tools/amp_reset_profile.py [done]"""
 import cProfile
 import io
 import pstats
@@ -35,12 +36,17 @@ for _ in range(k):
 host = (time.perf_counter() - t0) / k * 1e6
 torch.cuda.synchronize()
 print("reset_flagged + flag copy: host %.1f us, wall %.1f us per call" % (host, (time.perf_counter() - t0) / k * 1e6))
+which = sys.argv[1] if len(sys.argv) > 1 else "flagged"
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(k):
-    task.reset_flagged()
+    if which == "flagged":
+        task.reset_flagged()
+    else:  # the reference's sequence: nonzero() on the host, numpy draws
+        task.reset_buf.copy_(mask)
+        task.reset_done()
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(26)
 print(s.getvalue())
