@@ -413,6 +413,23 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
            "fetch_amp_obs_demo with device-side draws in one launch (igx_motion_fetch_amp_obs: the draws of "
            "igx_motion_sample and the batch of igx_motion_amp_obs_steps), %d trajectories x %d history steps per fetch; "
            "no host transfer, no synchronisation" % (nb, K))
+    if world > 1:
+        # the imitation batches of all ranks as one demo buffer: every fetch followed by an all-gather of the
+        # [512, 210] batch over the data group (RCCL when it is up)
+        from isaacgym_amd import distributed
+
+        def fetch_and_gather(i):
+            fetch(i)
+            return distributed.all_gather_rows(batch, group.data)
+        try:
+            us = timed(fetch_and_gather, 2 * steps)
+            rows = fetch_and_gather(0).shape[0]
+            report("amp_demo_fetch+all_gather", us, nb * K * world, None,
+                   "the same fetch on every rank followed by an all-gather of the [%d, %d] batches over %s: %d rows per "
+                   "gathered demo buffer, %d ranks (time per fetch + gather on the slowest rank, host clock of the "
+                   "enqueueing thread excluded: HIP events)" % (nb, K * 105, group.backend, rows, world))
+        except Exception as e:  # noqa: BLE001 - an extra line of the report must not cost the run its result
+            res["amp_demo_fetch+all_gather"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
     rec = TrajectoryRecorder(nb, K * 105, None, 4 * steps + WARMUP, dev)
 
     def fetch_and_stream(i):
@@ -558,6 +575,8 @@ def main():
             out["collectives"] = {"rendezvous_and_agreement": "gloo", "barrier": backend, "max_of_elapsed": backend}
             if es is not None or (configs and "humanoid_step+episode_stats" in configs):
                 out["collectives"]["episode_stats_all_gather"] = backend
+            if configs and "us" in configs.get("amp_demo_fetch+all_gather", {}):
+                out["collectives"]["imitation_batch_all_gather"] = backend
             if group.note:
                 out["collectives"]["note"] = group.note
         if configs is not None:

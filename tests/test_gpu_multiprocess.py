@@ -91,6 +91,9 @@ def test_bench_two_ranks_with_configs_run_the_sharded_humanoid_configuration():
     c = d["configs"]["humanoid_step+episode_stats"]
     assert c["us"] > 0 and c["bytes_per_unit"] == 940 + 28 and "2 ranks" in c["what"] and "over gloo" in c["what"]
     assert d["collectives"]["episode_stats_all_gather"] == "gloo"
+    g = d["configs"]["amp_demo_fetch+all_gather"]
+    assert g["us"] > 0 and g["units"] == 2 * 1024 and "1024 rows per gathered demo buffer" in g["what"], g
+    assert d["collectives"]["imitation_batch_all_gather"] == "gloo"
     for name in ("humanoid_step", "allegro_post", "humanoid_amp_step", "torch_jit_utils.slerp", "cartpole_step",
                  "shadow_post", "humanoid_imitate_step", "ant_imitate_step", "motion_amp_obs_1024"):
         assert d["configs"][name]["us"] > 0, name
