@@ -188,6 +188,12 @@ def test_amp_fuzz():
             t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=DEV)
         if trial % 3 == 2:
             _poison(rng, t, ("root_states", "dof_state", "rigid_body_state", "contact_forces"), 0.002)
+        if trial % 4 == 1:  # output buffers that are only 4-byte aligned (views one float into a larger allocation)
+            for k in ("obs", "amp_obs", "obs_clamped"):
+                if k in t:
+                    big = torch.zeros(t[k].numel() + 1, device=DEV)
+                    big[1:] = t[k].reshape(-1)
+                    t[k] = big[1:].view(t[k].shape)
         ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
         what = "amp trial %d n %d K %d%s" % (trial, n, K, " poisoned" if trial % 3 == 2 else "")
         ops.humanoid_amp_step(p, t, n)
