@@ -390,6 +390,7 @@ class HumanoidAMP(HumanoidAMPBase):
         """Everything the plan's structs were filled from: the tensor objects behind the buffer names (a name bound
         to another tensor is another buffer; where each object points is compared separately) and the parameters."""
         return (tuple(map(id, self._buffers().values())), id(self._initial_dof_pos), id(self._initial_dof_vel),
+                id(self._motion_lib), id(self._motion_lib._tables), id(self._motion_lib.sampling_cdf()),
                 int(seed), float(ref_prob), self._state_init, self._rng_dev(), self.env_offset, self._num_amp_obs_steps,
                 float(self.dt), bool(self._local_root_obs), tuple(self._kb), tuple(self._cb),
                 bool(self._enable_early_termination), float(self._termination_height), int(self.max_episode_length))
