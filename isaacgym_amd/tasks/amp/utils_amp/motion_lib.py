@@ -347,6 +347,8 @@ class MotionLib:
         stream order) once the ring has come round."""
         n = int(ids.shape[0])
         dev = self._device
+        if torch.device(dev).type != "cuda":  # no CPU path: the kernels behind every query take device memory
+            raise ValueError("libigx works on device tensors only (this MotionLib lives on %s)" % (dev,))
         if n == 0:
             return torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float64, device=dev)
         ring = self.__dict__.get("_stage_ring")
