@@ -231,3 +231,49 @@ def test_bad_arguments_raise():
         ops.action_stage(x, x.clone(), "force", gain=torch.ones(3, device=DEV))
     with pytest.raises(RuntimeError):
         ops.action_stage(x, x.clone(), "force", gain=torch.ones(4, device=DEV), clip_actions=-1.0)
+
+
+def test_extreme_values_through_the_wrappers():
+    """NaN, +-Inf, +-3e38, 1e30, 1e-30, subnormals and signed zeros in the actions, the observations and the
+    persistent noise draws: the action stage, the noise lambdas, the clamp and the step tail against the CPU
+    restatement (numpy, one rounding per operation, NaN-propagating minimum / maximum like torch.clamp)."""
+    rng = np.random.default_rng(11)
+    specials = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e30, -1e30, 1e-30, 1e-40, -1e-45, 0.0, -0.0, 1e19, 1e-20],
+                        np.float32)
+
+    def arr(n, frac=0.05):
+        x = rng.standard_normal(n).astype(np.float32) * 2
+        idx = rng.integers(0, n, max(1, int(n * frac)))
+        x[idx] = specials[rng.integers(0, len(specials), len(idx))]
+        return x
+
+    def same(got, want, what):
+        assert H.bit_equal_fraction(got, want) == 1.0, what
+
+    n = 4099
+    x, corr, fresh = arr(n), arr(n), arr(n)
+    for operation in ("additive", "scaling"):
+        spec = ops.NoiseSpec(dev(corr), 0.3, -0.1, 0.7, 0.05, operation, "gaussian")
+        out = torch.zeros(n, device=DEV)
+        ops.noise_apply(spec, dev(x), out=out, fresh=dev(fresh))
+        same(host(out), oracle.noise_apply(x, corr, fresh, 0.3, -0.1, 0.7, 0.05, operation), "noise " + operation)
+    envs = n // 7
+    a = arr(envs * 7)
+    gain, off = arr(7, 0.3), arr(7, 0.3)
+    for mode in ("force", "pd_target"):
+        keep, t = torch.zeros(envs * 7, device=DEV), torch.zeros(envs * 7, device=DEV)
+        ops.action_stage(dev(a), t, mode, gain=dev(gain), offset=dev(off), power_scale=0.37, clip_actions=1.5, actions_out=keep)
+        wa, wt = oracle.action_stage(a.reshape(envs, 7), mode, gain=gain, offset=off, power_scale=0.37, clip_actions=1.5)
+        same(host(keep), wa.reshape(-1), mode + " actions")
+        same(host(t), wt.reshape(-1), mode + " targets")
+    clamped = torch.zeros(n, device=DEV)
+    ops.clamp(dev(x), -1.25, 1.25, clamped)
+    assert torch.equal(torch.nan_to_num(clamped, nan=7.0), torch.nan_to_num(torch.clamp(dev(x), -1.25, 1.25), nan=7.0))
+    assert bool((clamped.isnan() == dev(x).isnan()).all())
+    obs = arr(envs * 7).reshape(envs, 7)
+    progress, reset = rng.integers(0, 40, envs), rng.integers(0, 2, envs)
+    out, to = torch.zeros(envs, 7, device=DEV), torch.zeros(envs, dtype=torch.bool, device=DEV)
+    ops.vec_task_tail(dev(obs), out, 2.5, dev(progress), dev(reset), to, 30)
+    want_obs, want_to = oracle.vec_task_tail(obs, 2.5, progress, reset, 30)
+    same(host(out), want_obs, "tail obs")
+    assert np.array_equal(host(to), want_to)
