@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/profile_round.sh <tag> and tools/profile_wide.sh <tag> left under gpurun_out/ into profiles/
-# under the round's names.  usage: tools/install_profiles.sh r03c r03 "<note on the build>"
+# under a common prefix.  usage: tools/install_profiles.sh <tag of the collection> <prefix in profiles/> "<note on the build>"
 set -eu
 TAG=$1; ROUND=$2; NOTE=${3:-}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel-trace stats of the default bench command plus
 # the PMC passes; writes compact summaries into profiles/ (tracked).
-# usage (on the GPU box): tools/profile_round.sh r01
+# usage (on the GPU box): tools/profile_round.sh <tag>
 set -u
-TAG=${1:-r00}
+TAG=${1:-t00}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/gpurun_out/profiles"

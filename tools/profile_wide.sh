@@ -1,9 +1,9 @@
 #!/bin/bash
 # Counters and kernel traces of the wide-row kernels as built: wave-level (SQ) counters and HBM traffic of the
 # HumanoidAMP step and the AllegroHand post-physics kernel, and a kernel trace of tools/bench_tasks.py for both.
-# usage (GPU box): tools/profile_wide.sh r03      -> gpurun_out/wide_<tag>/
+# usage (GPU box): tools/profile_wide.sh <tag>      -> gpurun_out/wide_<tag>/
 set -u
-TAG=${1:-r00}
+TAG=${1:-t00}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/wide_$TAG
 mkdir -p "$OUT"

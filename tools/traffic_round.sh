@@ -1,8 +1,8 @@
 #!/bin/bash
 # HBM traffic of the step kernels other than Ant's (tools/pmc_traffic.sh per kernel); summaries under gpurun_out/traffic_<tag>/
-# usage (GPU box): tools/traffic_round.sh r02
+# usage (GPU box): tools/traffic_round.sh <tag>
 set -u
-TAG=${1:-r00}
+TAG=${1:-t00}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/traffic_$TAG
 mkdir -p "$OUT"

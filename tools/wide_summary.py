@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Merge the counter summaries that tools/profile_wide.sh leaves under gpurun_out/wide_<tag>/ into one JSON with
-the derived shares per kernel.  usage: tools/wide_summary.py gpurun_out/wide_r03b > profiles/<name>.json"""
+the derived shares per kernel.  usage: tools/wide_summary.py gpurun_out/wide_<tag> > profiles/<name>.json"""
 import json
 import os
 import re
