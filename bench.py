@@ -497,20 +497,11 @@ def main():
         from isaacgym_amd.episode_stats import EpisodeStats
         es = EpisodeStats(n, dev)
 
-    step_events = []  # with --episode-stats: one event pair per step around the step kernel alone
-
-    def run(k0, k, timed=False):
+    def run(k0, k, with_stats=True):
         for i in range(k0, k0 + k):
             p.rng_offset = i
-            if es is not None and timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                step(p, sets[i % NUM_INPUT_SETS], n, caches[i % NUM_INPUT_SETS])
-                e1.record()
-                step_events.append((e0, e1))
-            else:
-                step(p, sets[i % NUM_INPUT_SETS], n, caches[i % NUM_INPUT_SETS])
-            if es is not None:
+            step(p, sets[i % NUM_INPUT_SETS], n, caches[i % NUM_INPUT_SETS])
+            if es is not None and with_stats:
                 es.step(sets[0]["rew"], sets[0]["reset"])
 
     def barrier():
@@ -524,13 +515,22 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(args.warmup, args.steps, timed=True)
+    run(args.warmup, args.steps)
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0  # this rank's K steps; the MAX over the ranks is taken below
     barrier()
-    if step_events:  # the episode kernels sit between ev0 and ev1: price the step kernel by its own pairs
-        kernel_ms = sum(a.elapsed_time(b) for a, b in step_events) / len(step_events)
+    if es is not None:
+        # the episode kernels sit between ev0 and ev1: the step kernel is priced by K more launches of its own, after
+        # the timed region (an event pair around every step of the timed loop would cost that loop a queue drain per
+        # event: measured 0.94 instead of 0.20 ms per step)
+        k0 = args.warmup + args.steps
+        ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev2.record()
+        run(k0, args.steps, with_stats=False)
+        ev3.record()
+        torch.cuda.synchronize()
+        kernel_ms = ev2.elapsed_time(ev3) / args.steps
     else:
         kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per launch on the launch stream
 
