@@ -233,6 +233,7 @@ def test_bad_arguments_raise():
         ops.action_stage(x, x.clone(), "force", gain=torch.ones(4, device=DEV), clip_actions=-1.0)
 
 
+@pytest.mark.filterwarnings("ignore:overflow encountered:RuntimeWarning")  # 3e38 times a gain: Inf on both sides, as intended
 def test_extreme_values_through_the_wrappers():
     """NaN, +-Inf, +-3e38, 1e30, 1e-30, subnormals and signed zeros in the actions, the observations and the
     persistent noise draws: the action stage, the noise lambdas, the clamp and the step tail against the CPU
