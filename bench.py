@@ -268,6 +268,9 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
 
     res = {}
 
+    def unit_rows(q):
+        return q / q.norm(dim=-1, keepdim=True)
+
     def report(name, us, units, bytes_per_unit, what):
         r = {"us": round(us, 2), "units": units, "units_per_s": units / us * 1e6, "what": what}
         if bytes_per_unit:
@@ -322,7 +325,20 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     report("humanoid_amp_step", timed(lambda i: ops.humanoid_amp_step(pm, sets[i % 2], n, caches[i % 2])), n, 2272,
            "HumanoidAMP post_physics_step (obs + reset + AMP history shift, 2 history steps), %d envs; 2960 B/env "
            "if the whole 780-B body rows are counted" % n)
-    del sets, caches
+    # reset_idx of the environments a masked list names (what the host-free reset hands over: entry i = environment i, -1
+    # = not reset), 0.3 % of them set: new state in, observation and every history slot out
+    gen = torch.Generator(device=dev).manual_seed(17 + rank)
+    every = torch.arange(n, device=dev)
+    masked = torch.where(torch.rand(n, device=dev, generator=gen) < 0.003, every, torch.full_like(every, -1))
+    f32 = dict(dtype=torch.float32, device=dev)
+    state = dict(root_pos=torch.randn(n, 3, generator=gen, **f32), root_rot=unit_rows(torch.randn(n, 4, generator=gen, **f32)),
+                 dof_pos=torch.randn(n, 28, generator=gen, **f32), root_vel=torch.randn(n, 3, generator=gen, **f32),
+                 root_ang_vel=torch.randn(n, 3, generator=gen, **f32), dof_vel=torch.randn(n, 28, generator=gen, **f32))
+    flagged = int((masked >= 0).sum())
+    report("humanoid_amp_reset_masked", timed(lambda i: ops.humanoid_amp_reset(pm, sets[i % 2], masked, state)), flagged, None,
+           "HumanoidAMP reset_idx through a masked list over %d environments, %d of them reset per launch (state in, "
+           "observation and AMP history out): resets/s" % (n, flagged))
+    del sets, caches, state, masked, every
 
     # the torch_jit_utils functions the path names, one launch each on 2^22 rows into preallocated outputs (three
     # rotating input sets: 2^22 rows of three sets do not stay in the 256 MB last-level cache)

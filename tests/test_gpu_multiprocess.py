@@ -74,7 +74,7 @@ def test_bench_world_of_one_through_rccl_with_configs():
     for name in ("humanoid_step", "allegro_post", "allegro_pre", "humanoid_amp_step", "motion_amp_obs_1024",
                  "motion_amp_obs_1048576", "amp_demo_fetch_device_sampling", "amp_demo_fetch_streamed_to_host",
                  "torch_jit_utils.quat_mul", "torch_jit_utils.tensor_clamp", "cartpole_step", "shadow_post",
-                 "humanoid_imitate_step", "ant_imitate_step"):
+                 "humanoid_imitate_step", "ant_imitate_step", "humanoid_amp_reset_masked"):
         assert d["configs"][name]["us"] > 0, name
     assert d["configs"]["humanoid_step"]["bytes_per_unit"] == 940 and "frac" in d["configs"]["humanoid_amp_step"]
 
