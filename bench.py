@@ -374,6 +374,26 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     caches = [dict() for _ in sets]
     report("cartpole_step", timed(lambda i: ops.cartpole_step(pc, sets[i % 4], n, caches[i % 4])), n, 68,
            "Cartpole observations + compute_cartpole_reward + resets, %d envs" % n)
+    # the fork's sampling mode on top of it (tasks/cartpole_sample.py:99-121): two observation columns of every
+    # environment per step, gathered on the device and streamed to pinned host memory on the recorder's side stream
+    from isaacgym_amd import _lib
+    from isaacgym_amd.recorder import TrajectoryRecorder as ColumnRecorder
+    caches = [dict() for _ in sets]
+    rsteps, rwarm = 32, 8
+    crec = ColumnRecorder(n, 4, {"x": 0, "theta": 2}, rsteps + rwarm, dev)
+
+    def step_and_capture(i):
+        ops.cartpole_step(pc, sets[i % 4], n, caches[i % 4])
+        crec.capture(sets[i % 4]["obs"])
+    us = timed(step_and_capture, rsteps, rwarm)
+    t0 = time.perf_counter()
+    _lib.check(_lib.lib().igx_recorder_sync(crec._h))
+    drain_ms = (time.perf_counter() - t0) * 1e3
+    report("cartpole_step+sample_capture", us, n, None,
+           "Cartpole step + capture of the x and theta columns of all %d environments (8 B per environment and step to "
+           "pinned host memory): time per step on the producer stream; %d steps = %.1f MB on the host %.2f ms after the "
+           "last step" % (n, crec.steps, 2 * 4 * n * crec.steps / 1e6, drain_ms))
+    crec.close()
     del sets, caches
     half = max(n // 2, 1)
     ps = synthetic.shadow_params("full_state", 1, 0)
