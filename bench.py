@@ -367,6 +367,23 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
         report("torch_jit_utils." + name, timed(fn), m, nbytes, "torch_jit_utils.%s, %d rows per launch" % (name, m))
     del Q, V, T, X, o4, o3, o8
 
+    # what VecTask.step does around a task's kernels when they do not fold it in: the action stage (clamp, self.actions,
+    # forces: tasks/base/vec_task.py:381-384 + tasks/ant.py:368-374) and the tail (clamped copy + time-outs, :404-416)
+    acts = [torch.randn(n, 8, device=dev, generator=gen) for _ in range(4)]
+    kept, forces = torch.empty(n, 8, device=dev), torch.empty(n, 8, device=dev)
+    gears = torch.rand(8, device=dev, generator=gen) * 100
+    report("action_stage_ant", timed(lambda i: ops.action_stage(acts[i % 4], forces, "force", gain=gears, power_scale=1.0,
+                                                                clip_actions=1.0, actions_out=kept)), n, 96,
+           "VecTask.step head + Ant.pre_physics_step: clamped actions kept, joint forces out, %d envs x 8 actions" % n)
+    obs4 = [torch.randn(n, 60, device=dev, generator=gen) for _ in range(4)]
+    obs_out = torch.empty(n, 60, device=dev)
+    prog = torch.randint(0, 1000, (n,), device=dev, generator=gen)
+    rst = torch.randint(0, 2, (n,), device=dev, generator=gen)
+    touts = torch.zeros(n, dtype=torch.bool, device=dev)
+    report("vec_task_tail_ant", timed(lambda i: ops.vec_task_tail(obs4[i % 4], obs_out, 5.0, prog, rst, touts, 1000)), n,
+           60 * 8 + 17, "VecTask.step tail on its own: clamped observation copy + time-out flags, %d envs x 60 columns" % n)
+    del acts, kept, forces, obs4, obs_out, prog, rst, touts
+
     # Cartpole (configuration 1's task on the GPU) and the tasks either side of the path's five: ShadowHand,
     # HumanoidImitate (2^19 environments: their rows are twice as wide), AntImitate with its exact quantile
     pc = synthetic.cartpole_params(1, 0)
