@@ -279,6 +279,11 @@ def motion_amp_obs_history(tables, motion_ids, motion_times, env_ids, num_steps,
                          (num_steps, _abi.IGX_AMP_OBS))
     if env_ids is None and amp_obs.numel() < n * num_steps * _abi.IGX_AMP_OBS:
         raise ValueError("igx_motion_amp_obs_history: amp_obs holds fewer environments than the lists")
+    if _lib.DEBUG_CHECKS and env_ids is not None and n:  # synchronises: the ids are device memory
+        envs = amp_obs.numel() // (num_steps * _abi.IGX_AMP_OBS)
+        if int(env_ids.max()) >= envs:
+            raise ValueError("igx_motion_amp_obs_history: env_ids reach %d, amp_obs holds %d environments" %
+                             (int(env_ids.max()), envs))
     with torch.cuda.device(dev):
         rc = _lib.lib().igx_motion_amp_obs_history(C.byref(tables), _lib.tensor_ptr(motion_ids, torch.int64),
                                                    _lib.tensor_ptr(motion_times, torch.float64),
