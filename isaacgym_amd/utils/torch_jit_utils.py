@@ -82,6 +82,10 @@ def calc_heading_quat_inv(q):  # :656-667
 
 def _affine(symbol, x, lower, upper):
     d = x.shape[-1]
+    if max(lower.dim(), upper.dim()) > 1 and x.numel() < 2 ** 31:
+        # bounds that vary along the leading dimensions too (the reference's expressions broadcast them):
+        # the whole array as one row, each element with a bound of its own
+        lower, upper, d = lower.expand(x.shape).reshape(-1), upper.expand(x.shape).reshape(-1), max(x.numel(), 1)
     xs = x.reshape(-1, d).contiguous().float()
     lo = lower.expand(d).contiguous().float()
     hi = upper.expand(d).contiguous().float()

@@ -65,6 +65,31 @@ def test_affine_vs_oracle_shapes(n, d, offset):
         assert H.bit_equal_fraction(got, ref) == 1.0, name
 
 
+def test_affine_bounds_per_element_and_strided_inputs():
+    """Bounds of the array's full shape (or any shape that broadcasts to it) and inputs that are views with
+    strides: the reference's expressions accept both (utils/torch_jit_utils.py:228-241)."""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(301, 7, generator=gen, device=DEV)
+    lo = -torch.rand(301, 7, generator=gen, device=DEV) - 0.1
+    hi = torch.rand(301, 1, generator=gen, device=DEV) + 0.1
+    for name in AFFINE:
+        got = getattr(tj, name)(x, lo, hi).cpu().numpy()
+        ref = oracle.affine(name, x.cpu().numpy().reshape(1, -1), lo.cpu().numpy().reshape(-1),
+                            hi.expand(301, 7).cpu().numpy().reshape(-1)).reshape(301, 7)
+        assert H.bit_equal_fraction(got, ref) == 1.0, name
+    wide = torch.randn(301, 14, generator=gen, device=DEV)
+    view, bounds = wide[:, ::2], torch.randn(2, 14, generator=gen, device=DEV).sort(dim=0).values[:, ::2]
+    for name in AFFINE:
+        got = getattr(tj, name)(view, bounds[0], bounds[1]).cpu().numpy()
+        ref = oracle.affine(name, view.contiguous().cpu().numpy(), bounds[0].contiguous().cpu().numpy(),
+                            bounds[1].contiguous().cpu().numpy())
+        assert H.bit_equal_fraction(got, ref) == 1.0, name
+    q = torch.randn(100, 8, generator=gen, device=DEV)
+    a, b = q[:, :4], q[:, 4:]  # rows 32 bytes apart
+    got = tj.quat_mul(a, b).cpu().numpy()
+    assert H.bit_equal_fraction(got, oracle.rowwise("quat_mul", a.contiguous().cpu().numpy(), b.contiguous().cpu().numpy())) == 1.0
+
+
 @pytest.mark.parametrize("n", [0, 1, 255, 257, 300001])
 def test_rowwise_vs_oracle_sizes(n):
     gen = torch.Generator(device=DEV).manual_seed(n + 5)
