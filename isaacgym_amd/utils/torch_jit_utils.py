@@ -13,10 +13,18 @@ import torch
 from .. import _lib
 
 
+def _f32(t):
+    """The kernels compute in fp32; a float64 input would come back with less precision than the reference's
+    result for it, so it is refused instead of being narrowed silently."""
+    if t.dtype == torch.float64:
+        raise TypeError("float64 input: the kernels behind these functions compute in float32")
+    return t.contiguous().float()
+
+
 def _rows(t, width):
     if t.shape[-1] != width:
         raise ValueError("expected last dimension %d, got shape %s" % (width, tuple(t.shape)))
-    return t.reshape(-1, width).contiguous().float()
+    return _f32(t.reshape(-1, width))
 
 
 def _run(symbol, ins, widths, out_width, out_shape):
@@ -86,9 +94,9 @@ def _affine(symbol, x, lower, upper):
         # bounds that vary along the leading dimensions too (the reference's expressions broadcast them):
         # the whole array as one row, each element with a bound of its own
         lower, upper, d = lower.expand(x.shape).reshape(-1), upper.expand(x.shape).reshape(-1), max(x.numel(), 1)
-    xs = x.reshape(-1, d).contiguous().float()
-    lo = lower.expand(d).contiguous().float()
-    hi = upper.expand(d).contiguous().float()
+    xs = _f32(x.reshape(-1, d))
+    lo = _f32(lower.expand(d))
+    hi = _f32(upper.expand(d))
     out = torch.empty_like(xs)
     _lib.call_affine(symbol, xs, lo, hi, out, xs.shape[0], d)
     return out.view(x.shape)

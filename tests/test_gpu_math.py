@@ -115,6 +115,15 @@ def test_rowwise_vs_oracle_sizes(n):
             H.assert_close(got, ref, scale=np.pi if name == "quat_to_exp_map" else 1.0, what=name)
 
 
+def test_float64_inputs_are_refused_not_narrowed():
+    q = torch.zeros(3, 4, dtype=torch.float64, device=DEV)
+    with pytest.raises(TypeError):
+        tj.quat_conjugate(q)
+    with pytest.raises(TypeError):
+        tj.scale(q, q[0], q[0])
+    assert tj.quat_conjugate(q.half()).dtype == torch.float32  # narrower types widen, as torch's promotion would
+
+
 def test_shapes_follow_the_reference():
     q = torch.randn(5, 15, 4, device=DEV)
     q = q / q.norm(dim=-1, keepdim=True)
