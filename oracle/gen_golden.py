@@ -23,7 +23,7 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_shim  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("IGX_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 CFG = os.path.join(ref_shim.IGE, "cfg", "task")
 
 
@@ -2314,5 +2314,6 @@ GENERATORS = {"nonunit": gen_nonunit, "imitate_extreme": gen_imitate_extreme, "e
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     names = sys.argv[1:] or [n for n in GENERATORS if n not in ("humanoid_imitate", "extract_positions", "imitate_extreme")]  # those need PYTORCH_JIT=0
+    names.sort(key=lambda n: n != "motion")  # amp_demo reads the clips motion.npz holds: that file first
     for n in names:
         GENERATORS[n]()
