@@ -16,6 +16,11 @@ fails on any rank ends every rank with a non-zero exit code; `--allow-gloo-fallb
 lets the barrier and the MAX run over gloo instead, and the JSON names the backend
 of every collective that was used (`collectives`, `rccl_ranks`).
 
+Before the W warm-up steps the run's own buffers take `--settle` untimed launches
+(100 by default, `config.settle_launches` in the JSON): a process's first ~75
+launches run 2-9 % slower than all the ones after them (tools/step_trend.py), and
+the steady state is what a training job lives in.  The K timed steps are exactly K.
+
 Rank 0 prints ONE JSON line.  `value` is whole-job env-steps/s with all inputs
 resident in HBM.  After the headline measurement the other configurations of the
 path (Humanoid, AllegroHand post / pre, HumanoidAMP step, motion-library samples)
@@ -47,6 +52,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed launches on the run's own buffers before the warm-up steps: the first ~75 launches "
+                         "of a process run 2-9 %% slower than the ones after them (tools/step_trend.py)")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--task", default="ant", choices=["ant", "humanoid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -246,8 +254,9 @@ def extra_configs(torch, dist, ops, synthetic, dev, n, steps, group, rank, world
     8 x 2^20 Humanoid environments with an RCCL all-gather of episode statistics)."""
     from isaacgym_amd.episode_stats import EpisodeStats
 
-    WARMUP = 40  # ten passes over the rotating sets before the clock starts (the first ~100 launches on freshly
-                 # allocated buffers run 2 % slower than the ones after them: tools/humanoid_spread.py)
+    WARMUP = 120  # the first ~75 launches of a kernel on freshly allocated buffers run 2-9 % slower than the ones
+                  # after them (tools/step_trend.py: Humanoid 182 / 172 / 168.5 us in launches 26-50 / 51-75 / 76-100,
+                  # 167.5 from there on): the clock starts in the steady state
 
     def timed(fn, k=steps, warmup=WARMUP):
         for i in range(warmup):
@@ -562,13 +571,14 @@ def main():
             dist.barrier(group=group.data)  # RCCL: an all-reduce on the device; gloo: host
         torch.cuda.synchronize()
 
-    run(0, args.warmup)
+    run(0, args.settle)  # steady state first: what a training job spends all but its first milliseconds in
+    run(args.settle, args.warmup)
     barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(args.warmup, args.steps)
+    run(args.settle + args.warmup, args.steps)
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0  # this rank's K steps; the MAX over the ranks is taken below
@@ -577,7 +587,7 @@ def main():
         # the episode kernels sit between ev0 and ev1: the step kernel is priced by K more launches of its own, after
         # the timed region (an event pair around every step of the timed loop would cost that loop a queue drain per
         # event: measured 0.94 instead of 0.20 ms per step)
-        k0 = args.warmup + args.steps
+        k0 = args.settle + args.warmup + args.steps
         ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev2.record()
         run(k0, args.steps, with_stats=False)
@@ -613,7 +623,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s obs/reward/reset fused post_physics_step, %d envs per GPU, AoS reference "
                                    "layout, in-kernel Philox resets" % (args.task, n),
-                       "envs_per_gpu": n, "global_envs": n * world, "input_sets": NUM_INPUT_SETS,
+                       "envs_per_gpu": n, "global_envs": n * world, "input_sets": NUM_INPUT_SETS, "settle_launches": args.settle,
                        "parallelism": "env-shard x%d (no data-path collective)" % world,
                        "collective_backend": backend},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
