@@ -25,7 +25,7 @@ t["hbm_bytes_per_launch"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_lau
 t["crosscheck_rdreq_bytes"] = (s["TCC_EA0_RDREQ_128B_sum"] * 128 + s["TCC_EA0_RDREQ_32B_sum"] * 32 +
                                (s["TCC_EA0_RDREQ_sum"] - s["TCC_EA0_RDREQ_128B_sum"] - s["TCC_EA0_RDREQ_32B_sum"]) * 64)
 t["crosscheck_wrreq_bytes"] = s["TCC_EA0_WRREQ_64B_sum"] * 64 + (s["TCC_EA0_WRREQ_sum"] - s["TCC_EA0_WRREQ_64B_sum"]) * 32
-t["source"] = ("profiles/%s_pmc_ant_step.json (rocprofv3 --pmc on `bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs`, "
+t["source"] = ("profiles/%s_pmc_ant_step.json (rocprofv3 --pmc on `bench.py --steps 6 --warmup 2 --settle 0 --no-cpu-baseline --no-configs`, "
                "one pass per counter group, tools/pmc_passes.sh; %s)" % (rnd, note))
 json.dump(t, open(root + "/profiles/traffic_ant.json", "w"), indent=1)
 for k, v in wide.items():

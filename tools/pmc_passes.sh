@@ -19,7 +19,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-configs "$@" > "$OUT/pass$i.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --settle 0 --no-cpu-baseline --no-configs "$@" > "$OUT/pass$i.log" 2>&1
   rc=$?
   echo "pass $i ($P) rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 "$OUT/pass$i.log"; exit 1; fi
