@@ -443,6 +443,22 @@ def knife_edge_joints(got_dof_pos, want_dof_pos):
     return g ^ w, w
 
 
+def half_turn_joints(got_dof_pos, want_dof_pos, ulps=4):
+    """exp_map_to_angle_axis keeps a rotation only if normalize_angle(|exp map|) > 1e-5 (no absolute value:
+    torch_jit_utils.py:570-587), so a three-DOF joint turned by pi comes out of dof_to_obs as that half turn when the
+    norm of its exp map rounds to pi or below, and as the identity when it rounds one ulp above (atan2 then gives
+    -pi).  quat_to_exp_map produces exactly such norms for w ~ 0; which side one lands on hangs on the last bit of
+    the library's acos.  Returns [n,J] bool: three-DOF joints whose exp-map norm is within `ulps` fp32 ulps of pi on
+    either side of the comparison."""
+    cols = amp_joint_columns("dof_pos")
+    tol = ulps * float(np.spacing(np.float32(np.pi)))
+
+    def near_pi(d):
+        return np.stack([(np.abs(np.linalg.norm(d[:, c].astype(np.float64), axis=-1) - np.pi) <= tol) if len(c) == 3
+                         else np.zeros(d.shape[0], bool) for c in cols], -1)
+    return near_pi(got_dof_pos) | near_pi(want_dof_pos)
+
+
 def assert_close_near_identity(x, ref, scale=1.0, rtol=RTOL, quantum=2e-2, what="", disagree=None, kind="dof_pos",
                                masked_want=None):
     """assert_close for quantities derived from quat_to_angle_axis(slerp(...)): every entry outside rtol must belong
