@@ -388,11 +388,15 @@ def amp_joint_columns(kind):
     return cols
 
 
-def amp_obs_errors(x, ref, copies_exact=True):
+def amp_obs_errors(x, ref, copies_exact=True, root_quat=None):
     """Per column group of an [n,105] AMP observation: max of |x - ref| / max(|ref|, natural scale), as an array
     over the entries (so a caller may exempt entries) plus the group table.  copies_exact=False holds the copied
     columns to the tolerance too (scale 1): for motion tables that were not taken from the recording but rebuilt by
-    the product's loader on this machine's host CPU, whose torch acos / sin may differ in the last bit."""
+    the product's loader on this machine's host CPU, whose torch acos / sin may differ in the last bit.
+    root_quat [n,4]: the root quaternions the observation was built from; a row whose quaternion is far from unit
+    length (poisoned state) has its root tan-norm columns judged at the scale of that quaternion's largest finite
+    component (squared): they are products of its components with heading-frame factors that may be as small as
+    1e-3, so the size of the outputs says nothing about the size of their rounding errors."""
     x = np.asarray(x, np.float64).reshape(-1, 105)
     ref = np.asarray(ref, np.float64).reshape(-1, 105)
     err = np.zeros_like(ref)
@@ -409,6 +413,10 @@ def amp_obs_errors(x, ref, copies_exact=True):
                 # simulator, of the size of |q|^2 for anything else (a poisoned state), which is then their scale
                 v = np.where(np.isfinite(ref[:, a:b]), np.abs(ref[:, a:b]), 0.0)
                 scale = np.maximum(1.0, v.max(-1, keepdims=True))
+                if root_quat is not None and a == 1:
+                    q = np.asarray(root_quat, np.float64).reshape(-1, 4)
+                    q = np.where(np.isfinite(q), np.abs(q), 0.0).max(-1, keepdims=True)
+                    scale = np.maximum(scale, q * q)
             if kind == "row":
                 v = np.where(np.isfinite(ref[:, a:b]), ref[:, a:b], 0.0).reshape(len(ref), -1, 3)
                 scale = np.sqrt((v * v).sum(-1)).max(-1, keepdims=True)
@@ -417,10 +425,10 @@ def amp_obs_errors(x, ref, copies_exact=True):
     return err
 
 
-def assert_amp_obs_close(x, ref, what="", rtol=RTOL, exempt=None, quiet=False, copies_exact=True):
+def assert_amp_obs_close(x, ref, what="", rtol=RTOL, exempt=None, quiet=False, copies_exact=True, root_quat=None):
     """The 1e-5 bar per column group, each group at its own natural scale; prints the largest error of every group
     (in units of the tolerance' denominator).  `exempt`: boolean [n,105] of entries left out (knife-edge joints)."""
-    err = amp_obs_errors(x, ref, copies_exact)
+    err = amp_obs_errors(x, ref, copies_exact, root_quat)
     if exempt is not None:
         err = np.where(exempt.reshape(err.shape), 0.0, err)
     worst = {name: (float(err[:, a:b].max()) if err.size else 0.0) for name, a, b, _ in AMP_OBS_GROUPS}

@@ -15,18 +15,7 @@ from tests import helpers as H  # noqa: E402
 from tests import test_gpu_fuzz as F  # noqa: E402
 
 want_trial = int(sys.argv[3])
-rng = np.random.default_rng(41 + F.SEED)
-for trial, n in enumerate(F._sizes(rng, 32, 10 * F.TRIALS)):
-    K = int(rng.choice([2, 2, 3, 4, 5]))
-    p = synthetic.amp_params(K, bool(rng.integers(2)), bool(rng.integers(2)), int(rng.integers(3, 400)))
-    p.termination_height = float(rng.uniform(0.2, 1.0))
-    t = synthetic.amp_state(n, int(rng.integers(1 << 30)), F.DEV, K, int(p.max_episode_length_m1) + 1)
-    if rng.integers(2):
-        p.clip_obs = float(rng.uniform(0.1, 3.0))
-        t["obs_clamped"] = torch.zeros(n, 105, device=F.DEV)
-        t["time_outs"] = torch.zeros(n, dtype=torch.bool, device=F.DEV)
-    if trial % 3 == 2:
-        F._poison(rng, t, ("root_states", "dof_state", "rigid_body_state", "contact_forces"), 0.002)
+for trial, n, K, p, t in F.amp_trials():
     if trial != want_trial:
         continue
     ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
@@ -37,7 +26,7 @@ for trial, n in enumerate(F._sizes(rng, 32, 10 * F.TRIALS)):
     got, want = t["obs"].cpu().numpy(), ref["obs"]
     err = H.amp_obs_errors(got, want)
     print("local_root_obs", p.local_root_obs, "n", n, "K", K)
-    for e in np.argsort(-np.nanmax(err[:, :13], axis=1))[:3]:
+    for e in np.argsort(-np.nan_to_num(np.nanmax(np.where(np.isnan(err[:, :13]), -1.0, err[:, :13]), axis=1)))[:3]:
         print("env", e, "max err", np.nanmax(err[e, :13]), "\n root", root[e].tolist(), "\n got ", got[e, :13].tolist(),
               "\n want", want[e, :13].tolist())
     break
