@@ -350,3 +350,78 @@ def test_ant_imitate_fuzz():
             H.assert_close(t["rew"].cpu().numpy(), ref["rew"], what=what + " rew")
             for k in ("dof_state", "potentials", "prev_potentials"):
                 assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, (k, what)
+
+
+def test_math_fuzz():
+    """torch_jit_utils: random batch sizes around the 256-row tile, magnitudes over six decades, quaternions off unit
+    length, and - every third trial - NaN / Inf / huge / tiny / subnormal entries.  Functions built from IEEE add / mul /
+    div / sqrt only must equal the CPU checker bit for bit whatever the input; the ones that pass through a math
+    library are held to 1e-5 on the finite, unit-quaternion trials."""
+    from isaacgym_amd.utils import torch_jit_utils as tj
+    from tests.test_oracle_math import OracleTJ
+    rng = np.random.default_rng(53 + SEED)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+    for trial, n in enumerate(_sizes(rng, 256, 6 * TRIALS)):
+        poisoned, nonunit = trial % 3 == 2, trial % 2 == 1
+
+        def quats():
+            q = rng.standard_normal((n, 4)).astype(np.float32)
+            q /= np.maximum(np.linalg.norm(q, axis=-1, keepdims=True), 1e-9).astype(np.float32)
+            return (q * np.float32(10.0 ** rng.uniform(-1, 1))) if nonunit else q
+
+        def vecs():
+            return (rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-3, 3, (n, 1))).astype(np.float32)
+
+        qa, qb, v, w, x = quats(), quats(), vecs(), vecs(), vecs()
+        if poisoned:
+            t = {k: dev(a) for k, a in dict(qa=qa, qb=qb, v=v, w=w, x=x).items()}
+            _poison(rng, t, tuple(t), 0.01)
+            qa, qb, v, w, x = (t[k].cpu().numpy() for k in ("qa", "qb", "v", "w", "x"))
+        pose = np.concatenate([x, qb], -1)
+        lo = -np.abs(vecs()[0]) - np.float32(0.1)
+        hi = np.abs(vecs()[0]) + np.float32(0.1)
+        what = "math trial %d n %d%s%s" % (trial, n, " poisoned" if poisoned else "", " nonunit" if nonunit else "")
+        exact = [("quat_mul", (qa, qb)), ("quat_rotate", (qa, v)), ("quat_rotate_inverse", (qa, v)), ("quat_conjugate", (qa,)),
+                 ("quat_to_tan_norm", (qa,)), ("quat_apply", (qa, v)), ("tf_inverse", (qa, v)), ("tf_combine", (qa, v, qb, w)),
+                 ("tf_apply", (qa, v, w)), ("tf_vector", (qa, v)), ("get_basis_vector", (qa, v)),
+                 ("compute_heading_and_up", (qa, qb, v, w, x, int(rng.integers(0, 3)))), ("local_to_world_space", (v, pose)),
+                 ("quat_axis", (qa, int(rng.integers(0, 3)))), ("normalize", (v,)), ("copysign", (float(rng.uniform(-3, 3)), v[:, 0])),
+                 ("scale", (v, lo, hi)), ("unscale", (v, lo, hi)), ("tensor_clamp", (v, lo, hi)), ("scale_transform", (v, lo, hi)),
+                 ("unscale_transform", (v, lo, hi)), ("saturate", (v, lo, hi))]
+        for name, args in exact:
+            got = getattr(tj, name)(*[dev(a) if isinstance(a, np.ndarray) else a for a in args])
+            got = tuple(g.cpu().numpy() for g in (got if isinstance(got, tuple) else (got,)))
+            if name in ("quat_mul", "quat_rotate", "quat_rotate_inverse", "quat_conjugate", "quat_to_tan_norm"):
+                ref = (oracle.rowwise(name, *args),)
+            elif name in ("scale", "unscale", "tensor_clamp"):
+                ref = (oracle.affine(name, *args),)
+            else:
+                ref = getattr(OracleTJ, name)(*args)
+                ref = ref if isinstance(ref, tuple) else (ref,)
+            for k, (a, b) in enumerate(zip(got, ref)):
+                assert H.bit_equal_fraction(a, b.reshape(a.shape)) == 1.0, (what, name, k)
+        # compute_rot: the two rotated vectors are exact whatever the input
+        got = tj.compute_rot(dev(qa), dev(v), dev(w), dev(x), dev(v))
+        ref = OracleTJ.compute_rot(qa, v, w, x, v)
+        for k in range(2):
+            assert H.bit_equal_fraction(got[k].cpu().numpy(), ref[k]) == 1.0, (what, "compute_rot", k)
+        if poisoned or nonunit:
+            continue
+        for k in range(2, 6):
+            H.assert_angle_close(got[k].cpu().numpy(), ref[k].reshape(got[k].shape), what=what + " compute_rot")
+        for a, b in zip(tj.get_euler_xyz(dev(qa)), OracleTJ.get_euler_xyz(qa)):
+            H.assert_angle_close(a.cpu().numpy(), b.reshape(a.shape), what=what + " get_euler_xyz")
+        tt = rng.uniform(-0.5, 1.5, (n, 1)).astype(np.float32)
+        small = (rng.standard_normal((n, 3)) * rng.uniform(0.01, 0.6, (n, 1))).astype(np.float32)  # exp maps below pi
+        for name, args, scale in (("slerp", (qa, qb, tt), 1.0), ("quat_to_exp_map", (qa,), np.pi),
+                                  ("exp_map_to_quat", (small,), 1.0), ("calc_heading_quat_inv", (qa,), 1.0)):
+            got1 = getattr(tj, name)(*[dev(a) for a in args]).cpu().numpy()
+            # (a half turn, w = 0 to the last bit, is +pi or -pi times the axis: the reference's edge, left out)
+            rows = np.abs(qa[:, 3]) > 1e-5 if name == "quat_to_exp_map" else slice(None)
+            H.assert_close(got1[rows], oracle.rowwise(name, *args)[rows], scale=scale, what=what + " " + name)
+        for name, args, scale in (("quat_diff_rad", (qa, qb), np.pi), ("calc_heading_quat", (qa,), 1.0)):
+            got1 = getattr(tj, name)(*[dev(a) for a in args]).cpu().numpy()
+            H.assert_close(got1, getattr(OracleTJ, name)(*args).reshape(got1.shape), scale=scale, what=what + " " + name)
