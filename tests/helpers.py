@@ -80,7 +80,7 @@ def bit_equal_fraction(x, ref):
     xf = np.ascontiguousarray(x, np.float32)
     rf = np.ascontiguousarray(ref, np.float32)
     same = (xf.view(np.uint32) == rf.view(np.uint32)) | (np.isnan(xf) & np.isnan(rf))
-    return float(same.mean())
+    return float(same.mean()) if same.size else 1.0
 
 
 def cartpole_params(meta, seed=0, rng_offset=0):

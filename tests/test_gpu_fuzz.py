@@ -425,3 +425,65 @@ def test_math_fuzz():
         for name, args, scale in (("quat_diff_rad", (qa, qb), np.pi), ("calc_heading_quat", (qa,), 1.0)):
             got1 = getattr(tj, name)(*[dev(a) for a in args]).cpu().numpy()
             H.assert_close(got1, getattr(OracleTJ, name)(*args).reshape(got1.shape), scale=scale, what=what + " " + name)
+
+
+def test_amp_reset_fuzz():
+    """HumanoidAMP reset_idx on a list: compact lists (sorted or shuffled), masked lists with -1 holes (entry i =
+    environment i), empty lists; any subset of the six state arrays given; both launch shapes of the kernel (lists
+    shorter and longer than 32 768 entries); poisoned state in every third trial."""
+    rng = np.random.default_rng(59 + SEED)
+    for trial, n in enumerate(_sizes(rng, 32, 8 * TRIALS)):
+        if trial % 16 == 7:
+            n = int(rng.integers(33000, 70000))  # the long-list launch shape
+        K = int(rng.choice([2, 3, 5]))
+        p = synthetic.amp_params(K, bool(rng.integers(2)), bool(rng.integers(2)), 300)
+        if rng.integers(2):
+            p.set("key_body_ids", [int(v) for v in rng.integers(0, 15, 4)])
+        t = synthetic.amp_state(n, int(rng.integers(1 << 30)), DEV, K, 301)
+        style = str(rng.choice(["compact", "shuffled", "masked", "empty"]))
+        frac = float(rng.choice([0.003, 0.1, 1.0]))
+        flagged = np.nonzero(rng.random(n) < frac)[0].astype(np.int64)
+        if style == "masked":
+            ids = np.where(np.isin(np.arange(n), flagged), np.arange(n), -1).astype(np.int64)
+        elif style == "empty":
+            ids = np.zeros(0, np.int64)
+        else:
+            ids = flagged.copy()
+            if style == "shuffled":
+                rng.shuffle(ids)
+        m = len(ids)
+        widths = dict(root_pos=3, root_rot=4, dof_pos=28, root_vel=3, root_ang_vel=3, dof_vel=28)
+        state_np = {}
+        for k, w in widths.items():
+            if rng.random() < 0.85:
+                a = rng.standard_normal((m, w)).astype(np.float32)
+                if k == "root_rot":
+                    a /= np.maximum(np.linalg.norm(a, axis=-1, keepdims=True), 1e-9).astype(np.float32)
+                if k == "dof_pos":
+                    a *= np.float32(0.6)
+                state_np[k] = a
+        state = {k: torch.from_numpy(v).to(DEV) for k, v in state_np.items()}
+        if trial % 3 == 2:
+            _poison(rng, state, tuple(state), 0.003)
+            _poison(rng, t, ("root_states", "dof_state", "rigid_body_state"), 0.002)
+            state_np = {k: v.cpu().numpy() for k, v in state.items()}
+        ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+        what = "amp reset trial %d n %d K %d %s m %d%s" % (trial, n, K, style, m, " poisoned" if trial % 3 == 2 else "")
+        ops.humanoid_amp_reset(p, t, torch.from_numpy(ids).to(DEV), state)
+        torch.cuda.synchronize()
+        oracle.humanoid_amp_reset(p, ref, ids, state_np)
+        for k in ("reset", "terminate", "progress"):
+            assert np.array_equal(t[k].cpu().numpy(), ref[k]), (k, what)
+        for k in ("root_states", "dof_state"):
+            assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0, (k, what)
+        touched = np.zeros(n, bool)
+        touched[ids[ids >= 0]] = True
+        got, want = t["obs"].cpu().numpy(), ref["obs"]
+        assert H.bit_equal_fraction(got[~touched], want[~touched]) == 1.0, what  # the others: not written
+        root_quat = ref["root_states"][:, 3:7]
+        if touched.any():
+            H.assert_amp_obs_close(got[touched], want[touched], what=what, quiet=True, root_quat=root_quat[touched])
+        ga, wa = t["amp_obs"].cpu().numpy(), ref["amp_obs"]
+        assert H.bit_equal_fraction(ga[~touched], wa[~touched]) == 1.0, what
+        for k in range(K):  # every history slot of a reset environment holds the new observation
+            assert H.bit_equal_fraction(ga[touched, k], got[touched]) == 1.0, (what, k)
