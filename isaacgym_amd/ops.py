@@ -154,8 +154,10 @@ def shadow_finalize_shards(params, tensors, records, num_steps=1):
 
 
 def motion_tables(tensors):
-    """igx_motion_tables from name -> device tensor (the caller keeps the tensors alive)."""
+    """igx_motion_tables from name -> device tensor.  The struct holds raw device addresses; the tensors they came
+    from ride along on the returned object (`_tensors`), so they live as long as it does."""
     t = _abi.MotionTables()
+    t._tensors = dict(tensors)
     t.num_motions = int(tensors["motion_length"].shape[0])
     for name, ctype in _abi.MotionTables._fields_:
         if ctype is _abi.ptr:

@@ -487,3 +487,61 @@ def test_amp_reset_fuzz():
         assert H.bit_equal_fraction(ga[~touched], wa[~touched]) == 1.0, what
         for k in range(K):  # every history slot of a reset environment holds the new observation
             assert H.bit_equal_fraction(ga[touched, k], got[touched]) == 1.0, (what, k)
+
+
+def test_reset_lists_and_sampling_fuzz():
+    """reset_idx of Cartpole / Ant / Humanoid on random id lists (sorted, shuffled, empty) with host-given or in-kernel
+    draws, and the motion library's device-side draws (plain and for flagged environments, all three state-init
+    modes): everything here is integer work, Philox and IEEE arithmetic, so bit for bit."""
+    rng = np.random.default_rng(61 + SEED)
+    g = H.load_golden("motion")
+    tabs_np = H.motion_tabs_from_golden(g)
+    tables = ops.motion_tables({k: torch.from_numpy(v).to(DEV) for k, v in tabs_np.items()})
+    cdf = np.cumsum(g["motion_weights"]) / np.sum(g["motion_weights"])
+    cdf_dev = torch.from_numpy(cdf).to(DEV)
+    for trial, n in enumerate(_sizes(rng, 64, 8 * TRIALS)):
+        seed, offset = int(rng.integers(1 << 40)), int(rng.integers(1 << 20))
+        m = int(n * float(rng.choice([0.0, 0.02, 0.5, 1.0])))
+        ids = rng.choice(n, size=m, replace=False).astype(np.int64)
+        if rng.integers(2):
+            ids.sort()
+        ids_dev = torch.from_numpy(ids).to(DEV)
+        what = "trial %d n %d m %d" % (trial, n, m)
+        with_rand = bool(rng.integers(2))
+        # Cartpole
+        p = synthetic.cartpole_params(seed=seed, rng_offset=offset)
+        t = synthetic.cartpole_state(n, int(rng.integers(1 << 30)), DEV, with_rand)
+        ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+        ops.cartpole_reset(p, t, ids_dev)
+        oracle.cartpole_reset(p, ref, ids)
+        for k in ("dof_state", "progress", "reset"):
+            assert np.array_equal(t[k].cpu().numpy().view(np.uint8), ref[k].view(np.uint8)), ("cartpole", k, what)
+        # Ant / Humanoid
+        for spec, reset in ((synthetic.ANT, ops.ant_reset), (synthetic.HUMANOID, ops.humanoid_reset)):
+            p = synthetic.loco_params(spec, seed=seed, rng_offset=offset)
+            p.dt = float(rng.uniform(0.005, 0.05))
+            p.set("targets", rng.uniform(-500, 500, 3).tolist())
+            t = synthetic.loco_state(spec, n, int(rng.integers(1 << 30)), DEV, with_rand)
+            if trial % 3 == 2:
+                _poison(rng, t, ("root_states", "dof_state", "potentials"), 0.01)
+            ref = {k: v.cpu().numpy().copy() for k, v in t.items()}
+            reset(p, t, ids_dev)
+            oracle.loco_reset(p, ref, ids)
+            for k in ("dof_state", "potentials", "prev_potentials", "progress", "reset", "root_states", "obs"):
+                assert H.bit_equal_fraction(t[k].cpu().numpy(), ref[k]) == 1.0 if ref[k].dtype == np.float32 else \
+                    np.array_equal(t[k].cpu().numpy(), ref[k]), (spec["name"] if "name" in spec else "loco", k, what)
+        # the motion library's draws
+        random_time, env_offset = bool(rng.integers(2)), int(rng.integers(0, 1 << 33))
+        mi = torch.empty(n, dtype=torch.int64, device=DEV)
+        mt = torch.empty(n, dtype=torch.float64, device=DEV)
+        ops.motion_sample(tables, cdf_dev, mi, mt, random_time=random_time, seed=seed, rng_offset=offset, env_offset=env_offset)
+        want = oracle.motion_sample(tabs_np, cdf, n, random_time, seed=seed, rng_offset=offset, env_offset=env_offset)
+        assert np.array_equal(mi.cpu().numpy(), want[0]) and np.array_equal(mt.cpu().numpy(), want[1]), ("sample", what)
+        flags = (rng.random(n) < float(rng.choice([0.0, 0.05, 1.0]))).astype(np.int64)
+        prob = float(rng.choice([0.0, 0.35, 1.0]))
+        env_ids, dflt = torch.empty_like(mi), torch.empty_like(mi)
+        ops.motion_sample_flagged(tables, cdf_dev, torch.from_numpy(flags).to(DEV), env_ids, mi, mt, random_time=random_time,
+                                  seed=seed, rng_offset=offset, ref_init_prob=prob, default_env_ids=dflt)
+        want = oracle.motion_sample_flagged(tabs_np, cdf, flags, random_time, seed, offset, prob)
+        for a, b, name in zip((env_ids, mi, mt, dflt), want, ("env_ids", "motion_ids", "motion_times", "default_env_ids")):
+            assert np.array_equal(a.cpu().numpy(), b), ("sample_flagged", name, what)
