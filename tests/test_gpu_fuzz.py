@@ -545,3 +545,73 @@ def test_reset_lists_and_sampling_fuzz():
         want = oracle.motion_sample_flagged(tabs_np, cdf, flags, random_time, seed, offset, prob)
         for a, b, name in zip((env_ids, mi, mt, dflt), want, ("env_ids", "motion_ids", "motion_times", "default_env_ids")):
             assert np.array_equal(a.cpu().numpy(), b), ("sample_flagged", name, what)
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")  # numpy announces the overflows and NaNs the poisoned trials are about
+def test_step_wrappers_fuzz():
+    """The action stage (noise, clamp, copy, scaling in its three modes), the stand-alone noise lambda and the step
+    tail on random shapes (1 - 40 actions or columns, bases that are only 4-byte aligned), random gains, clips and
+    noise parameters, poisoned entries in every third trial: plain IEEE arithmetic, so bit for bit."""
+    rng = np.random.default_rng(67 + SEED)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+    specials = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e30, 1e-30, 1e-40, -1e-45, 0.0, -0.0], np.float32)
+    for trial in range(20 * TRIALS):
+        envs, width, shift = int(rng.integers(1, 3000)), int(rng.integers(1, 41)), int(rng.integers(0, 2))
+        count = envs * width
+        frac = 0.02 if trial % 3 == 2 else 0.0
+
+        def arr(n, scale=1.0):
+            x = (rng.standard_normal(n) * scale).astype(np.float32)
+            if frac:
+                idx = rng.integers(0, n, max(1, int(n * frac)))
+                x[idx] = specials[rng.integers(0, len(specials), len(idx))]
+            return x
+
+        def shifted(a):  # the same values at a base one float into an allocation
+            return dev(np.concatenate([np.zeros(shift, np.float32), a]))[shift:]
+
+        what = "wrappers trial %d envs %d width %d shift %d%s" % (trial, envs, width, shift, " poisoned" if frac else "")
+        a, corr, fresh = arr(count, 2.0), arr(count), arr(count)
+        gain, off = arr(width, 3.0), arr(width)
+        power, clip = float(rng.uniform(0.1, 500.0)), float(rng.choice([np.inf, 1.0, 0.5, 3.0]))
+        operation = str(rng.choice(["additive", "scaling"]))
+        nz = [float(v) for v in rng.uniform(-1, 1, 4)]
+        noised = bool(rng.integers(2))
+        noise_np = dict(corr=corr, fresh=fresh, corr_scale=nz[0], corr_shift=nz[1], scale=nz[2], shift=nz[3], operation=operation)
+        for mode in ("force", "pd_target", "first_dof"):
+            num_dof = int(rng.integers(1, 5)) if mode == "first_dof" else 0
+            acts = a[:envs] if mode == "first_dof" else a
+            spec = ops.NoiseSpec(dev(corr[:acts.size]), nz[0], nz[1], nz[2], nz[3], operation, "gaussian") if noised else None
+            keep = torch.zeros(acts.size + shift, device=DEV)[shift:]
+            tgt = torch.full((envs * num_dof if mode == "first_dof" else acts.size,), 7.0, device=DEV)
+            ops.action_stage(shifted(acts), tgt, mode, gain=None if mode == "first_dof" else dev(gain),
+                             offset=dev(off) if mode == "pd_target" else None, power_scale=power, clip_actions=clip,
+                             actions_out=keep, noise=spec, fresh=dev(fresh[:acts.size]) if noised else None, num_dof=num_dof)
+            nn = dict(noise_np, corr=corr[:acts.size], fresh=fresh[:acts.size]) if noised else None
+            wa, wt = oracle.action_stage(acts if mode == "first_dof" else acts.reshape(envs, width), mode, gain=gain, offset=off,
+                                         power_scale=power, clip_actions=clip, num_dof=num_dof, noise=None if nn is None else
+                                         {k: (v if not isinstance(v, np.ndarray) else v.reshape(wshape(acts, mode, envs, width)))
+                                          for k, v in nn.items()})
+            assert H.bit_equal_fraction(keep.cpu().numpy(), wa.reshape(-1)) == 1.0, (what, mode, "actions")
+            assert H.bit_equal_fraction(tgt.cpu().numpy(), wt.reshape(-1)) == 1.0, (what, mode, "targets")
+        # the noise lambda on its own, and the tail
+        spec = ops.NoiseSpec(dev(corr), nz[0], nz[1], nz[2], nz[3], operation, "gaussian")
+        out = torch.zeros(count + shift, device=DEV)[shift:]
+        ops.noise_apply(spec, shifted(a), out=out, fresh=dev(fresh))
+        assert H.bit_equal_fraction(out.cpu().numpy(), oracle.noise_apply(a, corr, fresh, nz[0], nz[1], nz[2], nz[3], operation)) == 1.0, what
+        obs = a.reshape(envs, width)
+        limit = int(rng.integers(2, 60))
+        progress, reset = rng.integers(0, 70, envs), rng.integers(0, 2, envs)
+        clamped, to = torch.zeros(envs, width, device=DEV), torch.zeros(envs, dtype=torch.bool, device=DEV)
+        clip_obs = float(rng.uniform(0.1, 6.0))
+        ops.vec_task_tail(dev(obs), clamped, clip_obs, dev(progress), dev(reset), to, limit)
+        want_obs, want_to = oracle.vec_task_tail(obs, clip_obs, progress, reset, limit)
+        assert H.bit_equal_fraction(clamped.cpu().numpy(), want_obs) == 1.0, (what, "tail")
+        assert np.array_equal(to.cpu().numpy(), want_to), (what, "time_outs")
+
+
+def wshape(acts, mode, envs, width):
+    return (envs,) if mode == "first_dof" else (envs, width)
