@@ -615,3 +615,38 @@ def test_step_wrappers_fuzz():
 
 def wshape(acts, mode, envs, width):
     return (envs,) if mode == "first_dof" else (envs, width)
+
+
+def test_quantile_fuzz():
+    """igx_quantile_f64 and its windowed form against torch.quantile (fp64, linear interpolation): random sizes on
+    both sides of the one-block path, random q including 0 and 1, continuous values, heavy ties, signed zeros,
+    infinities, values packed into a few ulps, subnormals, and a NaN now and then; the windowed select with one
+    workspace kept across trials, as a task keeps it (its window then starts wherever the last data left it)."""
+    rng = np.random.default_rng(71 + SEED)
+    window_ws = torch.zeros(ops._abi.IGX_QUANTILE_WORKSPACE_BYTES // 8, dtype=torch.int64, device=DEV)
+    for trial in range(40 * TRIALS):
+        n = int(rng.choice([rng.integers(1, 70), rng.integers(1, 5000), rng.integers(4000, 300000)]))
+        kind = int(rng.integers(0, 7))
+        x = rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3)
+        if kind == 1:
+            x = np.round(x)                                   # ties, +0.0 and -0.0
+        elif kind == 2:
+            x[rng.random(n) < 0.2] = np.inf
+            x[rng.random(n) < 0.1] = -np.inf
+        elif kind == 3:
+            x = 1.0 + rng.integers(0, 6, n) * np.spacing(1.0)   # six neighbouring doubles
+        elif kind == 4:
+            x = rng.integers(-3, 4, n) * 4.9e-324              # subnormals of both signs
+        elif kind == 5:
+            x = np.full(n, float(rng.standard_normal()))
+        elif kind == 6 and rng.integers(2):
+            x[int(rng.integers(0, n))] = np.nan
+        q = float(rng.choice([0.0, 1.0, 0.99, 0.5, rng.random()]))
+        xt = torch.from_numpy(np.ascontiguousarray(x, np.float64))
+        want = float(torch.quantile(xt, q))
+        for name, got in (("select", float(ops.quantile_f64(xt.to(DEV), q))),
+                          ("windowed", float(ops.quantile_f64_windowed(xt.to(DEV), q, window_ws)))):
+            # (a zero result may carry either sign: among tied -0.0 and +0.0 torch's sort keeps the input order, the
+            # select orders by bit pattern; the two compare equal, which is what the caller's max(1.8, q) sees)
+            assert got == want or (np.isnan(got) and np.isnan(want)), \
+                ("quantile trial %d n %d kind %d q %r %s" % (trial, n, kind, q, name), got, want)
