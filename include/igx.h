@@ -41,7 +41,9 @@ extern "C" {
 
 typedef void *igx_stream_t; /* hipStream_t */
 
-/* Library identification and error text (no reference counterpart). */
+/* Library identification and error text (no reference counterpart).
+ * igx_version() = 100 * major + 10 * minor, 120 for this header: a binding that needs igx_motion_fetch_amp_obs,
+ * igx_motion_amp_obs_history or igx_extract_positions_from_rigid_body_states checks for >= 120. */
 int igx_version(void);
 const char *igx_last_error_string(void);
 

@@ -43,6 +43,8 @@ int tuning_int(const char *name, int dflt)
 
 }  // namespace igx
 
-extern "C" int igx_version(void) { return 110; }
+// 100 * major + 10 * minor.  1.2 added igx_motion_fetch_amp_obs, igx_motion_amp_obs_history and
+// igx_extract_positions_from_rigid_body_states (entry points only: every earlier signature and struct is unchanged).
+extern "C" int igx_version(void) { return 120; }
 
 extern "C" const char *igx_last_error_string(void) { return igx::error_buffer(); }

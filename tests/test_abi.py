@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string():
     lib = _lib.lib()
-    assert lib.igx_version() >= 100
+    assert lib.igx_version() >= 120  # the header's version: the three newest entry points are in
     assert isinstance(lib.igx_last_error_string(), bytes)
 
 
