@@ -20,6 +20,10 @@
  *  - Return value: 0 = ok, negative = IGX_E_* argument error (nothing was
  *    launched), positive = hipError_t of the failed launch.
  *    igx_last_error_string() describes the last error of the calling thread.
+ *  - Threads: entry points may be called from several host threads at once, each on its own stream and
+ *    buffers; the library keeps no state between calls apart from that per-thread error text, tuning
+ *    constants read once from the environment, and the device address of the one file-scope scratch array
+ *    (igx_allegro_post_physics_static, whose calls on one device share it and must not overlap).
  */
 #ifndef IGX_H
 #define IGX_H
